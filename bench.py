@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of the path-tracing hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
+
+A "step" is one complete render of the configuration (default: BASELINE config 4,
+dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
+max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
+one process per GPU with torch.distributed.run; frames are sharded over ranks and
+the accumulation buffers are summed with one RCCL all-reduce per step (strong
+scaling: total samples fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     - path (bounce) kernel: algorithmic bytes of the casts it executes
+                 (36 B per box test + 36 B per triangle test + 48 B per sphere per
+                 cast, reference layout and visit order, counted by an instrumented
+                 run of the same launches) / mean launch duration from HIP events on
+                 the library's stream, against the 8 TB/s HBM3E figure.
+  cpu_baseline - the CPU oracle (oracle/, a C restatement of the reference shader;
+                 the reference itself cannot run here) on a bounded sample of the
+                 same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
+L2_PEAK_GBS = 34500.0        # aggregate L2, measured figure of the microarchitecture guide
+MALL_PEAK_GBS = 8600.0       # Infinity Cache random-row gather figure of the same guide
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting pass")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import ShardedRenderer
+
+    cfg = scenes.config(args.config)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    spheres = scenes.spheres_for(cfg["spheres"])
+    W, H, rpp, n_frames = cfg["width"], cfg["height"], cfg["rays_per_pixel"], cfg["n_frames"]
+    spp = rpp * n_frames
+    samples_per_step = W * H * spp
+
+    def make_renderer(flags=0):
+        params = pkg.default_params(width=W, height=H, rays_per_pixel=rpp,
+                                    max_bounce_count=cfg["max_bounce_count"], flags=flags)
+        r = pkg.Renderer(params, device=local_rank)
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        return r
+
+    r = make_renderer()
+    info = r.scene_info()
+    sharded = ShardedRenderer(r, rank, world) if world > 1 else None
+
+    def step():
+        if sharded is not None:
+            sharded.render(0, n_frames)
+        else:
+            r.render_frames(0, n_frames)          # the reference protocol: running mean over frames
+            r.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    r.reset_timing()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing = r.timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    result = None
+    if rank == 0:
+        value = samples_per_step * args.steps / elapsed / 1e6
+        result = {
+            "metric": "Msamples/s at 1080p dragon_800k, 8 bounces",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": cfg["name"],
+                "note": "dragon_800k is absent from the reference; SYNTHETIC STAND-IN = dragon_80k with every "
+                        "triangle split 1->9, BVH from this repo's builder (max_depth %d)" % scenes.REGEN_MAX_DEPTH
+                        if cfg["mesh"] == "dragon_800k_synth" else "",
+                "resolution": [W, H], "spp": spp, "frames": n_frames, "rays_per_pixel": rpp,
+                "max_bounce_count": cfg["max_bounce_count"], "triangles": int(len(tris)),
+                "bvh_nodes": int(len(bvh)), "bvh_depth": info["bvh_depth"], "spheres": int(len(spheres)),
+                "parallelism": "frames sharded over %d GPU(s), one RCCL sum all-reduce per step" % world
+                               if world > 1 else "single GPU, running mean",
+            },
+            "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])
+                                    for k in ("primary_ms", "path_ms", "resolve_ms")},
+        }
+
+    # ---- roofline of the dominant kernel (rank 0) -------------------------
+    if rank == 0:
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                "traffic": None, "kernel": "path_kernel"}
+        if not args.no_count and timing["frames"]:
+            rc = make_renderer(pkg.PT_FLAG_COUNT_WORK)
+            frames_local = len(range(rank, n_frames, world))
+            if world > 1:
+                rc.render_frames_sum(rank, frames_local, world)
+            else:
+                rc.render_frames(0, n_frames)
+            cnt = rc.counters()
+            rc.close()
+            S = len(spheres)
+            path_bytes = 36 * cnt["path_kernel_box_tests"] + 36 * cnt["path_kernel_tri_tests"] \
+                + 48 * S * cnt["path_kernel_ray_casts"]
+            per_launch = path_bytes / frames_local
+            avg_ms = timing["path_ms"] / timing["frames"]
+            achieved = per_launch / (avg_ms * 1e-3) / 1e9
+            all_bytes = 36 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 48 * S * cnt["ray_casts"] \
+                + 32 * W * H * frames_local
+            roof.update({
+                "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms,
+                "launches_timed": int(timing["frames"]),
+                "ray_casts_per_launch": cnt["path_kernel_ray_casts"] / frames_local,
+                "box_tests_per_cast": cnt["path_kernel_box_tests"] / max(1, cnt["path_kernel_ray_casts"]),
+                "tri_tests_per_cast": cnt["path_kernel_tri_tests"] / max(1, cnt["path_kernel_ray_casts"]),
+                "frac_of_l2_peak": achieved / L2_PEAK_GBS, "frac_of_mall_peak": achieved / MALL_PEAK_GBS,
+                "whole_frame_algorithmic_bytes": all_bytes / frames_local,
+                "reference_ray_casts_per_step": cnt["ray_casts"] * (world if world > 1 else 1),
+                "rays_per_second": cnt["ray_casts"] / frames_local * n_frames * args.steps / elapsed,
+            })
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == cfg["name"]:
+                    roof["traffic"] = tj.get("path_kernel_hbm_bytes_per_launch")
+        result["roofline"] = roof
+
+    # ---- CPU baseline (rank 0, N = 1 only) --------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        om = entry.load_oracle_module()
+        oracle = om.Oracle(shared_math=False)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail)), 16))
+        op = oracle.default_params(width=W, height=H, rays_per_pixel=rpp, max_bounce_count=cfg["max_bounce_count"])
+        sc = oracle.scene(spheres, tris, bvh)
+        cpu_frames = min(n_frames, 2)
+        acc = np.zeros((H, W, 4), np.float32)
+        t0 = time.perf_counter()
+        oracle.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, cpu_frames,
+                             accum=acc, nthreads=cores)
+        cpu_s = time.perf_counter() - t0
+        cpu_samples = W * H * rpp * cpu_frames
+        result["cpu_baseline"] = {
+            "value": cpu_samples / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "frames 0..%d of %d of the same workload, all pixels (%.1f M of %.1f M samples), %.1f s; "
+                      "C restatement of shader.wgsl with OpenMP over rows (the reference needs wgpu and cannot run here)"
+                      % (cpu_frames - 1, n_frames, cpu_samples / 1e6, samples_per_step / 1e6, cpu_s),
+        }
+        # parity spot check of what was just timed: GPU running mean over the same frames
+        r.render_frames(0, cpu_frames)
+        gimg = r.read_accum(4)[..., :3]
+        err = np.abs(gimg - acc[..., :3])
+        ok = (err <= 2e-3 * np.abs(acc[..., :3]) + 1e-4).all(axis=-1).mean()
+        result["parity_spot_check"] = {"frames": cpu_frames, "pixels_within_2e-3_rel": float(ok),
+                                       "mean_rel_err_of_image_mean": float(abs(gimg.mean() - acc[..., :3].mean()) / acc[..., :3].mean())}
+
+    r.close()
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,205 @@
+/*
+ * pt_api.h - C ABI of the MI355X path-tracing backend (libpt_hip.so).
+ *
+ * The reference renderer (JacobScheff/Path-Tracing) has no FFI: its renderer
+ * boundary is the wgpu bind group of seven storage buffers, the shader's
+ * compile-time constants and one draw per frame.  Each entry point below
+ * replaces one piece of that contract; the reference location it stands in
+ * for is cited at the declaration.  Plain C types only: the header is meant to
+ * be consumed by bindgen / cgo / ctypes as it stands.
+ *
+ * Conventions
+ *   - every function returns PT_OK (0) or a negative PT_E* code and never
+ *     aborts; pt_last_error() returns the message of the last failure on that
+ *     context (or of the last failed pt_create when ctx is NULL);
+ *   - a pt_ctx is bound to one GPU and one HIP stream and is single-threaded;
+ *     distinct contexts may be driven from distinct host threads;
+ *   - scene arrays are COPIED at upload (like wgpu create_buffer_init), the
+ *     caller keeps ownership;
+ *   - all floats are IEEE binary32, files are little-endian.
+ */
+#ifndef PT_API_H
+#define PT_API_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK 0
+#define PT_EINVAL (-1)   /* bad argument / malformed scene file */
+#define PT_EHIP (-2)     /* a HIP runtime call failed (message has the HIP error string) */
+#define PT_ENOMEM (-3)
+#define PT_EIO (-4)      /* file could not be read */
+#define PT_ESTATE (-5)   /* call made in the wrong order (e.g. render before upload) */
+
+/* pt_params.flags */
+#define PT_FLAG_EXACT_MATH 1u  /* log/cos/pow from portable IEEE-only polynomials: radiance is then
+                                  reproducible bit for bit on a CPU; default is the hardware
+                                  transcendental instructions */
+#define PT_FLAG_COUNT_WORK 2u  /* kernels also count box tests / triangle tests / ray casts
+                                  (pt_get_counters); slower, for roofline accounting */
+
+typedef struct pt_ctx pt_ctx;
+
+/*
+ * Everything the reference fixes at pipeline-build time as WGSL `const`s:
+ * src/shaders/shader.wgsl:24-37 (counts, bounces, rays per pixel, screen size,
+ * fov), :48-54 (environment) and the triangle material hard-coded in
+ * ray_triangle, :283-286.  Counts of spheres/triangles/nodes are taken from
+ * pt_upload_scene instead, and bvh_max_depth is derived from the node file.
+ */
+typedef struct pt_params {
+    uint32_t width, height;          /* screen_size, shader.wgsl:35 */
+    uint32_t rays_per_pixel;         /* shader.wgsl:34 */
+    uint32_t max_bounce_count;       /* shader.wgsl:33; the bounce loop is inclusive (N+1 casts) */
+    float fov_degrees;               /* shader.wgsl:36 (60), converted with pi = 3.14159 */
+    float tri_color[3];              /* shader.wgsl:283 */
+    float tri_emission_color[3];     /* shader.wgsl:284 */
+    float tri_emission_strength;     /* shader.wgsl:285 */
+    float tri_smoothness;            /* shader.wgsl:286 */
+    float sky_horizon[3];            /* shader.wgsl:48 */
+    float sky_zenith[3];             /* shader.wgsl:49 */
+    float ground[3];                 /* shader.wgsl:50 */
+    float sun_dir[3];                /* shader.wgsl:51 (not normalised) */
+    float sun_intensity;             /* shader.wgsl:52 */
+    float sun_focus;                 /* shader.wgsl:53 */
+    uint32_t use_environment_lighting; /* shader.wgsl:54 */
+    uint32_t flags;                  /* PT_FLAG_* */
+} pt_params;
+
+/* Work counters (PT_FLAG_COUNT_WORK).  They follow the reference's traversal
+ * (shader.wgsl:169-235): box_tests = ray_box evaluations, tri_tests =
+ * ray_triangle evaluations, ray_casts = calculate_ray_collision calls the
+ * reference would make (one per bounce of every sample). */
+typedef struct pt_counters {
+    uint64_t ray_casts;
+    uint64_t box_tests;
+    uint64_t tri_tests;
+    uint64_t paths;
+    /* the part of the three counts above that the bounce/path kernel itself
+     * executed (casts after the primary one); used for that kernel's roofline */
+    uint64_t path_kernel_ray_casts;
+    uint64_t path_kernel_box_tests;
+    uint64_t path_kernel_tri_tests;
+} pt_counters;
+
+/* HIP-event timing of the kernels launched by the render calls since the last
+ * pt_reset_timing (events are recorded on the context's stream). */
+typedef struct pt_timing {
+    uint64_t frames;           /* frames rendered */
+    double primary_ms;         /* primary-ray kernel, summed */
+    double path_ms;            /* bounce/path kernel (the dominant one), summed */
+    double resolve_ms;         /* per-pixel resolve + accumulation kernel, summed */
+} pt_timing;
+
+/* Fills *p with the values the committed reference source uses
+ * (shader.wgsl:24-54, 283-286): 1200x600, 20 rays/pixel, 10 bounces, fov 60. */
+int pt_default_params(pt_params *p);
+
+/* Replaces State::new's device/pipeline creation (src/main.rs:144-190, 270-274):
+ * selects GPU `device_ordinal`, creates the stream and the zeroed accumulation
+ * buffer (main.rs:365-379; 16 bytes per pixel as the shader addresses it,
+ * shader.wgsl:41). */
+int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out);
+
+/* Replaces the sphere / triangle / BVH storage buffers, bindings 0, 5 and 6
+ * (src/main.rs:286-355, shader.wgsl:39,44,45).  spheres: sphere_count x 12 f32
+ * (x y z radius r g b er eg eb emission_strength smoothness, main.rs:286);
+ * triangles: triangle_count x 9 f32 (.bin contents); bvh: node_count x 9 f32
+ * (_bvh.bin contents: min.xyz max.xyz triangle_index triangle_count
+ * child_index, prepare_data/src/main.rs:181-192).  sphere_count may be 0.
+ * The node file is followed exactly as the shader follows it (including
+ * unreachable nodes and inner nodes whose ranges disagree with their
+ * children); links that leave the arrays are rejected with PT_EINVAL. */
+int pt_upload_scene(pt_ctx *ctx, const float *spheres, uint32_t sphere_count,
+                    const float *triangles, uint32_t triangle_count,
+                    const float *bvh, uint32_t node_count);
+
+/* Convenience for the include_bytes! pair of src/main.rs:323,342. */
+int pt_load_scene_files(pt_ctx *ctx, const char *triangles_bin, const char *bvh_bin,
+                        const float *spheres, uint32_t sphere_count);
+
+/* Replaces the camera position / rotation buffers, bindings 3 and 4, written
+ * every frame by State::render (src/main.rs:455-464).  Rotation in degrees,
+ * applied as in rotate_vector (shader.wgsl:327-348). */
+int pt_set_camera(pt_ctx *ctx, const float position[3], const float rotation_degrees[3]);
+
+/* Replaces the frame_count upload + the two draws + `frame_count += 1` of
+ * State::render (src/main.rs:448-452, 498-510), n_frames times: frame f uses
+ * frame_count = first_frame_count + f and folds its per-pixel mean into the
+ * accumulation buffer with weight 1/(frame_count+1) (shader.wgsl:104-106), so
+ * frame_count 0 overwrites the buffer.  Asynchronous on the context's stream. */
+int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames);
+
+/* Frame-sharded form for multi-GPU renders: ADDS the per-pixel mean of frames
+ * first_frame_count, +frame_stride, +2*frame_stride ... (n_frames of them) to
+ * the accumulation buffer instead of keeping a running mean.  Summing the
+ * buffers of all ranks and multiplying by 1/total_frames gives the running
+ * mean of shader.wgsl:104-106 up to f32 rounding.  No reference counterpart
+ * (the reference is single-GPU). */
+int pt_render_frames_sum(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames,
+                         uint32_t frame_stride);
+
+/* accum *= s (used by the root rank after the cross-GPU sum). */
+int pt_scale_accum(pt_ctx *ctx, float s);
+
+/* Reads binding 2, the accumulation buffer (shader.wgsl:41,105-106): row-major,
+ * row 0 on top, stride_floats = 3 (packed RGB) or 4 (the shader's 16-byte
+ * pixel stride).  Synchronises the stream first. */
+int pt_read_accum(pt_ctx *ctx, float *out, uint32_t stride_floats);
+
+/* Zero-fills the accumulation buffer (its initial state, main.rs:365-379). */
+int pt_reset_accum(pt_ctx *ctx);
+
+/* Lets the caller own the accumulation buffer: device_ptr must point to
+ * width*height*4 floats of device memory on this context's GPU (for example a
+ * torch tensor that a collective will reduce in place).  NULL switches back to
+ * the internal buffer.  pt_accum_device_ptr returns the buffer in use. */
+int pt_bind_accum(pt_ctx *ctx, void *device_ptr);
+void *pt_accum_device_ptr(pt_ctx *ctx);
+
+/* Debug / parity output with no reference counterpart (the shader's HitInfo,
+ * shader.wgsl:7-16, has no primitive id): closest hit of every pixel's primary
+ * ray.  prim_id = triangle index >= 0, -(1+sphere index) for spheres, INT32_MIN
+ * for a miss; distance as HitInfo.distance (1e6 on a miss).  Host arrays of
+ * width*height elements. */
+int pt_primary_hits(pt_ctx *ctx, int32_t *prim_id, float *distance);
+
+/* Blocks until the stream is idle. */
+int pt_synchronize(pt_ctx *ctx);
+
+int pt_get_counters(pt_ctx *ctx, pt_counters *out);  /* synchronises; needs PT_FLAG_COUNT_WORK */
+int pt_reset_counters(pt_ctx *ctx);
+int pt_get_timing(pt_ctx *ctx, pt_timing *out);      /* synchronises */
+int pt_reset_timing(pt_ctx *ctx);
+
+/* Scene facts derived at upload: depth of the node file walked from the root
+ * (the shader needs bvh_max_depth >= this, shader.wgsl:30,170), reachable inner
+ * nodes and leaves. */
+int pt_scene_info(pt_ctx *ctx, uint32_t *bvh_depth, uint32_t *inner_nodes, uint32_t *leaves);
+
+/* Replaces Rust drop of State. */
+void pt_destroy(pt_ctx *ctx);
+
+/* Replaces the unwrap()/expect() panics of the reference (src/main.rs:152-170). */
+const char *pt_last_error(pt_ctx *ctx);
+
+/*
+ * Offline BVH builder, replaces prepare_data/src/main.rs:14-136 + 179-220:
+ * top-down, 10 candidate planes x 3 axes per node, split by triangle centre,
+ * stops at max_depth or when the split does not lower the cost.  Pure host
+ * code.  triangles_out (triangle_count x 9 f32) receives the reordered
+ * triangles the reference writes back over its input .bin; *nodes_out is
+ * allocated by the library (free with pt_free) and holds *node_count x 9 f32
+ * in _bvh.bin layout.  The output is bit-identical to the reference builder's.
+ */
+int pt_bvh_build(const float *triangles_in, uint32_t triangle_count, int max_depth,
+                 float *triangles_out, float **nodes_out, uint32_t *node_count);
+void pt_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_API_H */

@@ -1,0 +1,286 @@
+"""Python host side of the MI355X path-tracing backend.
+
+A thin ctypes layer over libpt_hip.so (the C ABI in include/pt_api.h) plus
+`Renderer`, which mirrors the reference host's `State` (src/main.rs:17-41,
+144-433, 444-523): it owns the scene buffers, camera and frame counter and
+exposes `render()` with the reference's per-frame protocol.
+
+The directory name contains a hyphen, so load it with `load_package()` from
+`__graft_entry__` (or importlib) under the module name `path_tracing_amd`.
+
+There is no CPU fallback: if libpt_hip.so is missing or no gfx950 GPU is
+present, construction fails with an exception.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
+
+PT_OK = 0
+PT_FLAG_EXACT_MATH = 1
+PT_FLAG_COUNT_WORK = 2
+
+MISS_ID = -(2 ** 31)
+
+
+class PtParams(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("rays_per_pixel", C.c_uint32),
+        ("max_bounce_count", C.c_uint32), ("fov_degrees", C.c_float),
+        ("tri_color", C.c_float * 3), ("tri_emission_color", C.c_float * 3),
+        ("tri_emission_strength", C.c_float), ("tri_smoothness", C.c_float),
+        ("sky_horizon", C.c_float * 3), ("sky_zenith", C.c_float * 3), ("ground", C.c_float * 3),
+        ("sun_dir", C.c_float * 3), ("sun_intensity", C.c_float), ("sun_focus", C.c_float),
+        ("use_environment_lighting", C.c_uint32), ("flags", C.c_uint32),
+    ]
+
+
+class PtCounters(C.Structure):
+    _fields_ = [("ray_casts", C.c_uint64), ("box_tests", C.c_uint64),
+                ("tri_tests", C.c_uint64), ("paths", C.c_uint64),
+                ("path_kernel_ray_casts", C.c_uint64), ("path_kernel_box_tests", C.c_uint64),
+                ("path_kernel_tri_tests", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PtTiming(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("primary_ms", C.c_double),
+                ("path_ms", C.c_double), ("resolve_ms", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/pt_api.h declares
+API_SYMBOLS = [
+    "pt_default_params", "pt_create", "pt_upload_scene", "pt_load_scene_files", "pt_set_camera",
+    "pt_render_frames", "pt_render_frames_sum", "pt_scale_accum", "pt_read_accum", "pt_reset_accum",
+    "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
+    "pt_reset_counters", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
+    "pt_last_error", "pt_bvh_build", "pt_free",
+]
+
+
+class PtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"pt error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libpt_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make -C {_HERE}` (there is no CPU fallback)")
+    # PyTorch wheels bundle their own libamdhip64.so.7.  Two HIP runtimes in one
+    # process cannot see each other's allocations (pt_bind_accum on a torch tensor
+    # would fail), so torch is loaded first when it is installed: the dynamic linker
+    # then resolves this library's libamdhip64.so.7 dependency to the copy that is
+    # already mapped.  Without torch the system ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.pt_default_params.argtypes = [C.POINTER(PtParams)]
+    L.pt_create.argtypes = [C.c_int, C.POINTER(PtParams), C.POINTER(C.c_void_p)]
+    L.pt_upload_scene.argtypes = [C.c_void_p, fp, C.c_uint32, fp, C.c_uint32, fp, C.c_uint32]
+    L.pt_load_scene_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, fp, C.c_uint32]
+    L.pt_set_camera.argtypes = [C.c_void_p, fp, fp]
+    L.pt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pt_render_frames_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.pt_scale_accum.argtypes = [C.c_void_p, C.c_float]
+    L.pt_read_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
+    L.pt_reset_accum.argtypes = [C.c_void_p]
+    L.pt_bind_accum.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_accum_device_ptr.argtypes = [C.c_void_p]
+    L.pt_accum_device_ptr.restype = C.c_void_p
+    L.pt_primary_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
+    L.pt_synchronize.argtypes = [C.c_void_p]
+    L.pt_get_counters.argtypes = [C.c_void_p, C.POINTER(PtCounters)]
+    L.pt_reset_counters.argtypes = [C.c_void_p]
+    L.pt_get_timing.argtypes = [C.c_void_p, C.POINTER(PtTiming)]
+    L.pt_reset_timing.argtypes = [C.c_void_p]
+    L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pt_destroy.argtypes = [C.c_void_p]
+    L.pt_destroy.restype = None
+    L.pt_last_error.argtypes = [C.c_void_p]
+    L.pt_last_error.restype = C.c_char_p
+    L.pt_bvh_build.argtypes = [fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32)]
+    L.pt_free.argtypes = [C.c_void_p]
+    L.pt_free.restype = None
+    _lib = L
+    return L
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def default_params(**overrides):
+    """pt_params initialised to the committed reference constants
+    (shader.wgsl:24-54, 283-286), with keyword overrides."""
+    p = PtParams()
+    rc = load_library().pt_default_params(C.byref(p))
+    if rc:
+        raise PtError(rc, "pt_default_params")
+    for k, v in overrides.items():
+        cur = getattr(p, k)
+        if hasattr(cur, "__len__"):
+            setattr(p, k, (C.c_float * 3)(*[float(x) for x in v]))
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def bvh_build(triangles, max_depth):
+    """Host BVH builder (prepare_data/src/main.rs). Returns (reordered_triangles[n,9], nodes[m,9])."""
+    L = load_library()
+    tr = np.ascontiguousarray(np.asarray(triangles, dtype=np.float32).reshape(-1, 9))
+    out_tr = np.empty_like(tr)
+    nodes_p = C.POINTER(C.c_float)()
+    n = C.c_uint32()
+    rc = L.pt_bvh_build(_fp(tr), tr.shape[0], int(max_depth), _fp(out_tr), C.byref(nodes_p), C.byref(n))
+    if rc:
+        raise PtError(rc, "pt_bvh_build failed")
+    nodes = np.ctypeslib.as_array(nodes_p, shape=(n.value, 9)).copy()
+    L.pt_free(nodes_p)
+    return out_tr, nodes
+
+
+class Renderer:
+    """Mirror of the reference's `State` (src/main.rs:17-41).
+
+    render()            -> State::render (main.rs:444-523): one frame, frame_count += 1
+    set_camera()/reset  -> update_camera's "any input resets frame_count" rule (main.rs:47-49)
+    """
+
+    def __init__(self, params, device=0):
+        self._L = load_library()
+        self.params = params
+        self._ctx = C.c_void_p()
+        rc = self._L.pt_create(int(device), C.byref(params), C.byref(self._ctx))
+        if rc:
+            raise PtError(rc, self._L.pt_last_error(None).decode())
+        self.frame_count = 0                       # main.rs:420
+        self.camera_position = [200.0, 0.0, 200.0]  # main.rs:382
+        self.camera_rotation = [0.0, 90.0, 0.0]     # main.rs:383
+        self.width, self.height = params.width, params.height
+
+    # -- plumbing --------------------------------------------------------
+    def _check(self, rc):
+        if rc:
+            raise PtError(rc, self._L.pt_last_error(self._ctx).decode())
+
+    def close(self):
+        if self._ctx:
+            self._L.pt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene (main.rs:286-355) ----------------------------------------
+    def upload_scene(self, spheres, triangles, bvh):
+        sp = np.ascontiguousarray(np.asarray(spheres, dtype=np.float32).reshape(-1, 12))
+        tr = np.ascontiguousarray(np.asarray(triangles, dtype=np.float32).reshape(-1, 9))
+        bv = np.ascontiguousarray(np.asarray(bvh, dtype=np.float32).reshape(-1, 9))
+        self._check(self._L.pt_upload_scene(self._ctx, _fp(sp), sp.shape[0], _fp(tr), tr.shape[0],
+                                            _fp(bv), bv.shape[0]))
+
+    def load_scene_files(self, triangles_bin, bvh_bin, spheres=()):
+        sp = np.ascontiguousarray(np.asarray(spheres, dtype=np.float32).reshape(-1, 12))
+        self._check(self._L.pt_load_scene_files(self._ctx, os.fsencode(triangles_bin), os.fsencode(bvh_bin),
+                                                _fp(sp), sp.shape[0]))
+
+    def scene_info(self):
+        d, i, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._L.pt_scene_info(self._ctx, C.byref(d), C.byref(i), C.byref(l)))
+        return {"bvh_depth": d.value, "inner_nodes": i.value, "leaves": l.value}
+
+    # -- camera (main.rs:45-115, 455-464) ---------------------------------
+    def set_camera(self, position, rotation_degrees, reset=True):
+        self.camera_position = [float(x) for x in position]
+        self.camera_rotation = [float(x) for x in rotation_degrees]
+        self._check(self._L.pt_set_camera(self._ctx, _f3(position), _f3(rotation_degrees)))
+        if reset:
+            self.frame_count = 0          # main.rs:47-49
+
+    # -- frames ------------------------------------------------------------
+    def render(self, n_frames=1):
+        """State::render n times (main.rs:444-523)."""
+        self._check(self._L.pt_render_frames(self._ctx, self.frame_count, int(n_frames)))
+        self.frame_count += int(n_frames)   # main.rs:510
+
+    def render_frames(self, first_frame_count, n_frames):
+        self._check(self._L.pt_render_frames(self._ctx, int(first_frame_count), int(n_frames)))
+
+    def render_frames_sum(self, first_frame_count, n_frames, frame_stride=1):
+        self._check(self._L.pt_render_frames_sum(self._ctx, int(first_frame_count), int(n_frames), int(frame_stride)))
+
+    def scale_accum(self, s):
+        self._check(self._L.pt_scale_accum(self._ctx, float(s)))
+
+    def reset_accum(self):
+        self._check(self._L.pt_reset_accum(self._ctx))
+
+    def read_accum(self, stride_floats=4):
+        out = np.empty((self.height, self.width, stride_floats), dtype=np.float32)
+        self._check(self._L.pt_read_accum(self._ctx, _fp(out), stride_floats))
+        return out
+
+    def bind_accum(self, device_ptr):
+        self._check(self._L.pt_bind_accum(self._ctx, C.c_void_p(device_ptr)))
+
+    def accum_device_ptr(self):
+        return self._L.pt_accum_device_ptr(self._ctx)
+
+    def primary_hits(self):
+        ids = np.empty((self.height, self.width), dtype=np.int32)
+        dist = np.empty((self.height, self.width), dtype=np.float32)
+        self._check(self._L.pt_primary_hits(self._ctx, ids.ctypes.data_as(C.POINTER(C.c_int32)), _fp(dist)))
+        return ids, dist
+
+    def synchronize(self):
+        self._check(self._L.pt_synchronize(self._ctx))
+
+    def counters(self):
+        c = PtCounters()
+        self._check(self._L.pt_get_counters(self._ctx, C.byref(c)))
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self._L.pt_reset_counters(self._ctx))
+
+    def timing(self):
+        t = PtTiming()
+        self._check(self._L.pt_get_timing(self._ctx, C.byref(t)))
+        return t.as_dict()
+
+    def reset_timing(self):
+        self._check(self._L.pt_reset_timing(self._ctx))

@@ -1,0 +1,603 @@
+/*
+ * Host side of libpt_hip.so: the C ABI of include/pt_api.h.
+ *
+ * Mirrors what State::new / State::render do around the shader in the
+ * reference (src/main.rs:286-409 buffer construction, :444-523 per-frame
+ * protocol), with the wgpu buffers replaced by HIP device memory and the two
+ * draws by three kernel launches per frame.
+ */
+#include "../../include/pt_api.h"
+#include "pt_internal.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EventPair { hipEvent_t start, stop; int kind; };
+
+}  // namespace
+
+struct pt_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    pt_params params{};
+    float cam_pos[3] = {200.0f, 0.0f, 200.0f};      /* src/main.rs:382 */
+    float cam_rot[3] = {0.0f, 90.0f, 0.0f};         /* src/main.rs:383 */
+
+    PTInnerRecord *d_inner = nullptr;
+    PTTriRecord *d_tris = nullptr;
+    float *d_spheres = nullptr;
+    uint32_t *d_big = nullptr;
+    float4 *d_accum_own = nullptr;
+    float4 *d_accum = nullptr;
+    PTHitRecord *d_hits = nullptr;
+    PTControl *d_ctrl = nullptr;
+    float4 *d_samples = nullptr;
+    unsigned long long *d_counters = nullptr;
+    int32_t *d_ids = nullptr;
+    float *d_dist = nullptr;
+
+    bool scene_loaded = false;
+    uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
+    uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
+    int stack_entries = 0;
+
+    std::vector<EventPair> pending;    /* recorded, not yet read */
+    std::vector<EventPair> free_events;
+    pt_timing timing{};
+
+    std::string err;
+};
+
+namespace {
+
+int fail(pt_ctx *c, int code, const std::string &msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int fail_hip(pt_ctx *c, hipError_t e, const char *what) {
+    return fail(c, PT_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(ctx, call)                                              \
+    do {                                                                \
+        hipError_t e_ = (call);                                         \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);        \
+    } while (0)
+
+template <typename T> void dev_free(T *&p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+/* ---- node file -> inner records --------------------------------------- */
+struct Repacked {
+    std::vector<PTInnerRecord> inner;
+    std::vector<uint32_t> big;     /* per-triangle count table, only when a leaf has >= 127 triangles */
+    uint32_t root_ref = 0, depth = 0, leaves = 0;
+};
+
+bool finite_nonneg_int(float f) { return f >= 0.0f && f <= 16777216.0f && f == std::floor(f); }
+
+/* leaf reference for node `n` of the file; returns false on a malformed range */
+bool leaf_ref(const float *node, uint32_t tri_count, Repacked &out, uint32_t &ref, std::string &why) {
+    if (!finite_nonneg_int(node[6]) || !(node[7] >= 0.0f) || !(node[6] + node[7] <= 16777216.0f)) {
+        why = "leaf with a negative, fractional or non-finite triangle range";
+        return false;
+    }
+    /* the shader loops i = u32(node[6]) .. u32(node[6] + node[7]) (shader.wgsl:186) */
+    uint32_t first = (uint32_t)node[6];
+    uint32_t end = (uint32_t)(node[6] + node[7]);
+    uint32_t count = end > first ? end - first : 0;
+    if ((uint64_t)first + count > tri_count) { why = "leaf triangle range leaves the triangle array"; return false; }
+    if (first >= (1u << 24)) { why = "triangle index does not fit 24 bits"; return false; }
+    if (count >= PT_REF_COUNT_ESCAPE) {
+        if (out.big.empty()) out.big.assign(tri_count ? tri_count : 1, 0);
+        out.big[first] = count;
+        ref = PT_REF_LEAF | (PT_REF_COUNT_ESCAPE << 24) | first;
+    } else {
+        ref = PT_REF_LEAF | (count << 24) | first;
+    }
+    return true;
+}
+
+/*
+ * Walks the file from node 0 exactly as the shader would (leaf iff
+ * node[8] == 0, children i32(node[8]) and i32(node[8] + 1), shader.wgsl:184,
+ * 197-198), numbering reachable inner nodes in depth-first pre-order.  A node
+ * reached twice (the legacy dragon_8k file has such links) is converted once.
+ * Cycles and links outside the array are errors.
+ */
+bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Repacked &out, std::string &why) {
+    const uint32_t UNSEEN = 0xffffffffu, OPEN = 0xfffffffeu, LEAF_SEEN = 0xfffffffdu;
+    std::vector<uint32_t> rec_of(node_count, UNSEEN);   /* inner record index per file node */
+    std::vector<uint32_t> height(node_count, 0);
+    std::vector<uint32_t> leafref(node_count, 0);
+    struct Frame { uint32_t node, a, b, rec; int stage; };
+    std::vector<Frame> st;
+
+    const float *root = bvh;
+    if (root[8] == 0.0f) {
+        if (!leaf_ref(root, tri_count, out, out.root_ref, why)) return false;
+        out.depth = 0; out.leaves = 1;
+        return true;
+    }
+    auto open = [&](uint32_t n) -> bool {
+        const float *node = bvh + 9 * (size_t)n;
+        float cf = node[8];
+        if (!(cf >= 1.0f) || !(cf < 2147483000.0f)) { why = "inner node with a child link outside the node array"; return false; }
+        int32_t ia = (int32_t)cf, ib = (int32_t)(cf + 1.0f);
+        if (ia <= 0 || ib <= 0 || (uint32_t)ia >= node_count || (uint32_t)ib >= node_count) {
+            why = "inner node with a child link outside the node array";
+            return false;
+        }
+        rec_of[n] = OPEN;
+        Frame f = {n, (uint32_t)ia, (uint32_t)ib, (uint32_t)out.inner.size(), 0};
+        out.inner.emplace_back();
+        st.push_back(f);
+        return true;
+    };
+    if (!open(0)) return false;
+    while (!st.empty()) {
+        const size_t top = st.size() - 1;
+        if (st[top].stage < 2) {
+            const uint32_t c = st[top].stage == 0 ? st[top].a : st[top].b;
+            st[top].stage++;
+            const float *cn = bvh + 9 * (size_t)c;
+            if (cn[8] == 0.0f) {
+                if (rec_of[c] == UNSEEN) {
+                    if (!leaf_ref(cn, tri_count, out, leafref[c], why)) return false;
+                    rec_of[c] = LEAF_SEEN;
+                    out.leaves++;
+                }
+            } else if (rec_of[c] == UNSEEN) {
+                if (st.size() > 4096) { why = "node file deeper than 4096 levels"; return false; }
+                if (!open(c)) return false;
+            } else if (rec_of[c] == OPEN) {
+                why = "node file contains a cycle";
+                return false;
+            }
+            continue;
+        }
+        /* both children converted: fill this node's record */
+        const Frame f = st[top];
+        const float *na = bvh + 9 * (size_t)f.a, *nb = bvh + 9 * (size_t)f.b;
+        const bool leaf_a = na[8] == 0.0f, leaf_b = nb[8] == 0.0f;
+        uint32_t ra = leaf_a ? leafref[f.a] : rec_of[f.a];
+        uint32_t rb = leaf_b ? leafref[f.b] : rec_of[f.b];
+        uint32_t ha = leaf_a ? 0 : height[f.a];
+        uint32_t hb = leaf_b ? 0 : height[f.b];
+        PTInnerRecord &r = out.inner[f.rec];
+        r.q[0] = make_float4(na[0], na[1], na[2], na[3]);
+        r.q[1] = make_float4(na[4], na[5], nb[0], nb[1]);
+        r.q[2] = make_float4(nb[2], nb[3], nb[4], nb[5]);
+        float fa, fb;
+        memcpy(&fa, &ra, 4); memcpy(&fb, &rb, 4);
+        r.q[3] = make_float4(fa, fb, 0.0f, 0.0f);
+        height[f.node] = 1 + (ha > hb ? ha : hb);
+        rec_of[f.node] = f.rec;
+        st.pop_back();
+    }
+    if (out.inner.size() >= 0x80000000u) { why = "too many inner nodes"; return false; }
+    out.root_ref = rec_of[0];
+    out.depth = height[0];
+    return true;
+}
+
+void build_tri_records(const float *tris, uint32_t n, std::vector<PTTriRecord> &out) {
+    out.resize(n ? n : 1);
+    for (uint32_t i = 0; i < n; i++) {
+        const float *t = tris + 9 * (size_t)i;
+        /* shader.wgsl:262-264, same operations in the same order */
+        float abx = t[3] - t[0], aby = t[4] - t[1], abz = t[5] - t[2];
+        float acx = t[6] - t[0], acy = t[7] - t[1], acz = t[8] - t[2];
+        float nx = aby * acz - abz * acy;
+        float ny = abz * acx - abx * acz;
+        float nz = abx * acy - aby * acx;
+        out[i].q[0] = make_float4(t[0], t[1], t[2], abx);
+        out[i].q[1] = make_float4(aby, abz, acx, acy);
+        out[i].q[2] = make_float4(acz, nx, ny, nz);
+    }
+}
+
+int validate_params(const pt_params *p, std::string &why) {
+    if (!p) { why = "params is NULL"; return PT_EINVAL; }
+    if (p->width == 0 || p->height == 0 || p->width > 16384 || p->height > 16384) { why = "width/height must be in 1..16384"; return PT_EINVAL; }
+    /* pixel_index is computed in f32 (shader.wgsl:83) and must stay exact */
+    if ((uint64_t)p->width * p->height + p->width > (1ull << 23)) { why = "width*height too large for the shader's f32 pixel index (2^23)"; return PT_EINVAL; }
+    if (p->rays_per_pixel == 0 || p->rays_per_pixel > 1024) { why = "rays_per_pixel must be in 1..1024"; return PT_EINVAL; }
+    if (p->max_bounce_count > 1000000) { why = "max_bounce_count too large"; return PT_EINVAL; }
+    if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) { why = "fov_degrees must be in (0,180)"; return PT_EINVAL; }
+    return PT_OK;
+}
+
+void fill_kernel_params(const pt_ctx *c, uint32_t frame_count, uint32_t accum_mode, PTKernelParams &k) {
+    memset(&k, 0, sizeof(k));
+    const pt_params &p = c->params;
+    k.width = p.width; k.height = p.height;
+    k.rays_per_pixel = p.rays_per_pixel; k.max_bounce_count = p.max_bounce_count;
+    k.frame_count = frame_count; k.accum_mode = accum_mode;
+    k.width_f = (float)p.width; k.height_f = (float)p.height;
+    /* vs_main, shader.wgsl:36-37,68-69.  fov is a const-expression of abstract
+     * floats (f64, rounded once); tan is taken in double and rounded once. */
+    float fov = (float)((double)p.fov_degrees * 3.14159 / 180.0);
+    float aspect = (float)p.width / (float)p.height;
+    k.screen_w = (float)std::tan((double)(fov * 0.5f)) * 2.0f;
+    k.screen_h = k.screen_w / aspect;
+    for (int i = 0; i < 3; i++) k.cam_pos[i] = c->cam_pos[i];
+    /* rotate_vector, shader.wgsl:332-341: angle * 3.14159 / 180 in f32 */
+    float a = c->cam_rot[0] * 3.14159f / 180.0f;
+    float b = c->cam_rot[1] * 3.14159f / 180.0f;
+    float cc = c->cam_rot[2] * 3.14159f / 180.0f;
+    k.cos_a = (float)std::cos((double)a); k.sin_a = (float)std::sin((double)a);
+    k.cos_b = (float)std::cos((double)b); k.sin_b = (float)std::sin((double)b);
+    k.cos_c = (float)std::cos((double)cc); k.sin_c = (float)std::sin((double)cc);
+    for (int i = 0; i < 3; i++) {
+        k.tri_color[i] = p.tri_color[i];
+        k.tri_emission_color[i] = p.tri_emission_color[i];
+        k.sky_horizon[i] = p.sky_horizon[i];
+        k.sky_zenith[i] = p.sky_zenith[i];
+        k.ground[i] = p.ground[i];
+    }
+    k.tri_emission_strength = p.tri_emission_strength;
+    k.tri_smoothness = p.tri_smoothness;
+    /* -normalize(sun_light_direction), shader.wgsl:395 */
+    float sx = p.sun_dir[0], sy = p.sun_dir[1], sz = p.sun_dir[2];
+    float inv = 1.0f / std::sqrt(sx * sx + sy * sy + sz * sz);
+    k.neg_sun[0] = -(sx * inv); k.neg_sun[1] = -(sy * inv); k.neg_sun[2] = -(sz * inv);
+    k.sun_intensity = p.sun_intensity; k.sun_focus = p.sun_focus;
+    k.use_env = p.use_environment_lighting ? 1u : 0u;
+    k.sphere_count = c->sphere_count;
+    k.root_ref = c->root_ref;
+    k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
+    k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
+    k.out_ids = c->d_ids; k.out_dist = c->d_dist; k.counters = c->d_counters;
+}
+
+int get_event_pair(pt_ctx *c, EventPair &ep) {
+    if (!c->free_events.empty()) { ep = c->free_events.back(); c->free_events.pop_back(); return PT_OK; }
+    HIP_TRY(c, hipEventCreate(&ep.start));
+    HIP_TRY(c, hipEventCreate(&ep.stop));
+    return PT_OK;
+}
+
+int drain_events(pt_ctx *c) {
+    for (EventPair &ep : c->pending) {
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, ep.start, ep.stop));
+        if (ep.kind == 0) c->timing.primary_ms += ms;
+        else if (ep.kind == 1) c->timing.path_ms += ms;
+        else c->timing.resolve_ms += ms;
+        c->free_events.push_back(ep);
+    }
+    c->pending.clear();
+    return PT_OK;
+}
+
+struct Timed {
+    pt_ctx *c; EventPair ep; bool ok;
+    Timed(pt_ctx *ctx, int kind) : c(ctx), ok(false) {
+        if (get_event_pair(c, ep) == PT_OK) { ep.kind = kind; ok = hipEventRecord(ep.start, c->stream) == hipSuccess; }
+    }
+    void done() { if (ok) { (void)hipEventRecord(ep.stop, c->stream); c->pending.push_back(ep); } }
+};
+
+int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, uint32_t mode) {
+    if (!c) return PT_EINVAL;
+    if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const bool exact = (c->params.flags & PT_FLAG_EXACT_MATH) != 0;
+    const bool count = (c->params.flags & PT_FLAG_COUNT_WORK) != 0;
+    for (uint32_t f = 0; f < n_frames; f++) {
+        PTKernelParams k;
+        fill_kernel_params(c, first + f * stride, mode, k);
+        HIP_TRY(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(PTControl), c->stream));
+        { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, c->stack_entries, exact, count, false, c->stream)); t.done(); }
+        { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, c->stack_entries, exact, count, c->num_cus, c->stream)); t.done(); }
+        { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
+        c->timing.frames++;
+        if (c->pending.size() > 3000) {       /* bound the number of live events on long renders */
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            int rc = drain_events(c);
+            if (rc) return rc;
+        }
+    }
+    return PT_OK;
+}
+
+bool read_file(const char *path, std::vector<float> &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (n < 0 || n % 4) { fclose(f); return false; }
+    out.resize((size_t)n / 4);
+    size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    return got == (size_t)n;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pt_default_params(pt_params *p) {
+    if (!p) return PT_EINVAL;
+    memset(p, 0, sizeof(*p));
+    p->width = 1200; p->height = 600;
+    p->rays_per_pixel = 20;
+    p->max_bounce_count = 10;
+    p->fov_degrees = 60.0f;
+    p->tri_color[0] = 0.65f; p->tri_color[1] = 0.65f; p->tri_color[2] = 1.0f;
+    p->tri_emission_strength = 0.0f;
+    p->tri_smoothness = 0.9f;
+    p->sky_horizon[0] = 0.5f; p->sky_horizon[1] = 0.7f; p->sky_horizon[2] = 1.0f;
+    p->sky_zenith[0] = 0.1f; p->sky_zenith[1] = 0.25f; p->sky_zenith[2] = 1.0f;
+    p->ground[0] = p->ground[1] = p->ground[2] = 0.2f;
+    p->sun_dir[0] = 0.0f; p->sun_dir[1] = -0.4f; p->sun_dir[2] = 0.5f;
+    p->sun_intensity = 3.0f; p->sun_focus = 200.0f;
+    p->use_environment_lighting = 1;
+    p->flags = 0;
+    return PT_OK;
+}
+
+int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
+    if (!out) return fail(nullptr, PT_EINVAL, "out is NULL");
+    *out = nullptr;
+    std::string why;
+    int rc = validate_params(params, why);
+    if (rc) return fail(nullptr, rc, why);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceCount");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail(nullptr, PT_EINVAL, "device ordinal out of range");
+    pt_ctx *c = new (std::nothrow) pt_ctx();
+    if (!c) return fail(nullptr, PT_ENOMEM, "out of host memory");
+    c->device = device_ordinal;
+    c->params = *params;
+    auto bail = [&](hipError_t he, const char *what) {
+        int r = fail_hip(nullptr, he, what);
+        pt_destroy(c);
+        return r;
+    };
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess) return bail(e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess) return bail(e, "hipGetDeviceProperties");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        { fail(nullptr, PT_EHIP, std::string("unsupported GPU architecture ") + prop.gcnArchName + " (built for gfx950)"); pt_destroy(c); return PT_EHIP; }
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    const size_t npix = (size_t)params->width * params->height;
+    if ((e = hipMalloc(&c->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
+    if ((e = hipMemsetAsync(c->d_accum_own, 0, npix * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset(accum)");
+    c->d_accum = c->d_accum_own;
+    if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
+    if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
+    if ((e = hipMalloc(&c->d_samples, npix * params->rays_per_pixel * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(samples)");
+    if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    *out = c;
+    return PT_OK;
+}
+
+int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
+                    const float *triangles, uint32_t triangle_count,
+                    const float *bvh, uint32_t node_count) {
+    if (!c) return PT_EINVAL;
+    if (sphere_count && !spheres) return fail(c, PT_EINVAL, "spheres is NULL");
+    if (triangle_count && !triangles) return fail(c, PT_EINVAL, "triangles is NULL");
+    if (!bvh || node_count == 0) return fail(c, PT_EINVAL, "a BVH with at least one node is required");
+    if (triangle_count > (1u << 24)) return fail(c, PT_EINVAL, "more than 2^24 triangles (indices are f32 in the node file)");
+    if (sphere_count > 65536) return fail(c, PT_EINVAL, "too many spheres");
+    Repacked rp;
+    std::string why;
+    if (!repack_nodes(bvh, node_count, triangle_count, rp, why)) return fail(c, PT_EINVAL, "malformed BVH file: " + why);
+    int need = (int)rp.depth + 1;            /* array<i32, bvh_max_depth + 1>, shader.wgsl:170 */
+    if (need > pt_max_stack_entries())
+        return fail(c, PT_EINVAL, "BVH depth " + std::to_string(rp.depth) + " exceeds the supported traversal stack");
+    std::vector<PTTriRecord> trec;
+    build_tri_records(triangles, triangle_count, trec);
+
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->scene_loaded = false;
+    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
+    size_t n_inner = rp.inner.size() ? rp.inner.size() : 1;
+    HIP_TRY(c, hipMalloc(&c->d_inner, n_inner * sizeof(PTInnerRecord)));
+    if (!rp.inner.empty())
+        HIP_TRY(c, hipMemcpy(c->d_inner, rp.inner.data(), rp.inner.size() * sizeof(PTInnerRecord), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&c->d_tris, trec.size() * sizeof(PTTriRecord)));
+    HIP_TRY(c, hipMemcpy(c->d_tris, trec.data(), trec.size() * sizeof(PTTriRecord), hipMemcpyHostToDevice));
+    size_t n_sph = sphere_count ? sphere_count : 1;
+    HIP_TRY(c, hipMalloc(&c->d_spheres, n_sph * 12 * sizeof(float)));
+    if (sphere_count)
+        HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, (size_t)sphere_count * 12 * sizeof(float), hipMemcpyHostToDevice));
+    if (rp.big.empty()) rp.big.assign(1, 0);
+    HIP_TRY(c, hipMalloc(&c->d_big, rp.big.size() * sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpy(c->d_big, rp.big.data(), rp.big.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->sphere_count = sphere_count; c->tri_count = triangle_count; c->node_count = node_count;
+    c->root_ref = rp.root_ref; c->depth = rp.depth;
+    c->inner_count = (uint32_t)rp.inner.size(); c->leaf_count = rp.leaves;
+    c->stack_entries = need;
+    c->scene_loaded = true;
+    return PT_OK;
+}
+
+int pt_load_scene_files(pt_ctx *c, const char *triangles_bin, const char *bvh_bin,
+                        const float *spheres, uint32_t sphere_count) {
+    if (!c) return PT_EINVAL;
+    if (!triangles_bin || !bvh_bin) return fail(c, PT_EINVAL, "file name is NULL");
+    std::vector<float> tri, bvh;
+    if (!read_file(triangles_bin, tri)) return fail(c, PT_EIO, std::string("cannot read ") + triangles_bin);
+    if (!read_file(bvh_bin, bvh)) return fail(c, PT_EIO, std::string("cannot read ") + bvh_bin);
+    if (tri.size() % 9) return fail(c, PT_EINVAL, "triangle file is not a multiple of 36 bytes");
+    if (bvh.size() % 9 || bvh.empty()) return fail(c, PT_EINVAL, "BVH file is not a non-empty multiple of 36 bytes");
+    return pt_upload_scene(c, spheres, sphere_count, tri.data(), (uint32_t)(tri.size() / 9),
+                           bvh.data(), (uint32_t)(bvh.size() / 9));
+}
+
+int pt_set_camera(pt_ctx *c, const float position[3], const float rotation_degrees[3]) {
+    if (!c) return PT_EINVAL;
+    if (!position || !rotation_degrees) return fail(c, PT_EINVAL, "camera pointer is NULL");
+    for (int i = 0; i < 3; i++) { c->cam_pos[i] = position[i]; c->cam_rot[i] = rotation_degrees[i]; }
+    return PT_OK;
+}
+
+int pt_render_frames(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames) {
+    return render_impl(c, first_frame_count, n_frames, 1, 0);
+}
+
+int pt_render_frames_sum(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames, uint32_t frame_stride) {
+    if (c && frame_stride == 0) return fail(c, PT_EINVAL, "frame_stride must be >= 1");
+    return render_impl(c, first_frame_count, n_frames, frame_stride, 1);
+}
+
+int pt_scale_accum(pt_ctx *c, float s) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, pt_launch_scale(c->d_accum, c->params.width * c->params.height, s, c->stream));
+    return PT_OK;
+}
+
+int pt_read_accum(pt_ctx *c, float *out, uint32_t stride_floats) {
+    if (!c) return PT_EINVAL;
+    if (!out || (stride_floats != 3 && stride_floats != 4)) return fail(c, PT_EINVAL, "out is NULL or stride_floats is not 3 or 4");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stride_floats == 4) {
+        HIP_TRY(c, hipMemcpy(out, c->d_accum, npix * sizeof(float4), hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(npix * 4);
+        HIP_TRY(c, hipMemcpy(tmp.data(), c->d_accum, npix * sizeof(float4), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < npix; i++) { out[3 * i] = tmp[4 * i]; out[3 * i + 1] = tmp[4 * i + 1]; out[3 * i + 2] = tmp[4 * i + 2]; }
+    }
+    return PT_OK;
+}
+
+int pt_reset_accum(pt_ctx *c) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->params.width * c->params.height * sizeof(float4), c->stream));
+    return PT_OK;
+}
+
+int pt_bind_accum(pt_ctx *c, void *device_ptr) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!device_ptr) { c->d_accum = c->d_accum_own; return PT_OK; }
+    if (((uintptr_t)device_ptr & 15u) != 0) return fail(c, PT_EINVAL, "accumulation buffer must be 16-byte aligned");
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, device_ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, PT_EINVAL, "pointer is not known to the HIP runtime"); }
+    if (attr.type != hipMemoryTypeDevice || attr.device != c->device)
+        return fail(c, PT_EINVAL, "pointer is not device memory of this context's GPU");
+    c->d_accum = (float4 *)device_ptr;
+    return PT_OK;
+}
+
+void *pt_accum_device_ptr(pt_ctx *c) { return c ? (void *)c->d_accum : nullptr; }
+
+int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
+    if (!c) return PT_EINVAL;
+    if (!prim_id || !distance) return fail(c, PT_EINVAL, "output pointer is NULL");
+    if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    if (!c->d_ids) HIP_TRY(c, hipMalloc(&c->d_ids, npix * sizeof(int32_t)));
+    if (!c->d_dist) HIP_TRY(c, hipMalloc(&c->d_dist, npix * sizeof(float)));
+    PTKernelParams k;
+    fill_kernel_params(c, 0, 0, k);
+    HIP_TRY(c, pt_launch_primary(k, c->stack_entries, true, false, true, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(prim_id, c->d_ids, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(distance, c->d_dist, npix * sizeof(float), hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
+int pt_synchronize(pt_ctx *c) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_get_counters(pt_ctx *c, pt_counters *out) {
+    if (!c) return PT_EINVAL;
+    if (!out) return fail(c, PT_EINVAL, "out is NULL");
+    if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[8];
+    HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    out->ray_casts = h[0]; out->box_tests = h[1]; out->tri_tests = h[2]; out->paths = h[3];
+    out->path_kernel_ray_casts = h[4]; out->path_kernel_box_tests = h[5]; out->path_kernel_tri_tests = h[6];
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_ctx *c) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    return PT_OK;
+}
+
+int pt_get_timing(pt_ctx *c, pt_timing *out) {
+    if (!c) return PT_EINVAL;
+    if (!out) return fail(c, PT_EINVAL, "out is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    *out = c->timing;
+    return PT_OK;
+}
+
+int pt_reset_timing(pt_ctx *c) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    int rc = drain_events(c);
+    if (rc) return rc;
+    c->timing = pt_timing{};
+    return PT_OK;
+}
+
+int pt_scene_info(pt_ctx *c, uint32_t *bvh_depth, uint32_t *inner_nodes, uint32_t *leaves) {
+    if (!c) return PT_EINVAL;
+    if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
+    if (bvh_depth) *bvh_depth = c->depth;
+    if (inner_nodes) *inner_nodes = c->inner_count;
+    if (leaves) *leaves = c->leaf_count;
+    return PT_OK;
+}
+
+void pt_destroy(pt_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (EventPair &ep : c->pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+    for (EventPair &ep : c->free_events) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
+    dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
+    dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *pt_last_error(pt_ctx *c) {
+    return c ? c->err.c_str() : g_create_error.c_str();
+}
+
+}  // extern "C"

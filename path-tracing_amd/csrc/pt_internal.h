@@ -1,0 +1,83 @@
+/* Internal declarations shared by the host side (pt_host.cpp) and the gfx950
+ * kernels (pt_kernels.hip).  Not part of the public ABI. */
+#ifndef PT_INTERNAL_H
+#define PT_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+/* Child reference stored in an inner record and on the traversal stack.
+ *   bit 31 clear: index of an inner record
+ *   bit 31 set  : leaf; bits 0-23 first triangle, bits 24-30 triangle count,
+ *                 count field 127 = "look the count up in big_leaf_count[first]" */
+#define PT_REF_LEAF 0x80000000u
+#define PT_REF_COUNT_ESCAPE 127u
+
+/* One inner node of the reference file, repacked so that ONE 64-byte record
+ * holds everything a visit needs: both child boxes and both child references.
+ * (The reference reads the two 36-byte child nodes, 72 bytes at 36-byte
+ * stride, and then re-reads a child when it is popped.)
+ *   q0 = (A.min.x, A.min.y, A.min.z, A.max.x)
+ *   q1 = (A.max.y, A.max.z, B.min.x, B.min.y)
+ *   q2 = (B.min.z, B.max.x, B.max.y, B.max.z)
+ *   q3 = (refA, refB, 0, 0) as raw bits
+ * Box values are copied verbatim from the file, so ray_box sees the same
+ * operands as the shader. */
+struct PTInnerRecord { float4 q[4]; };
+
+/* One triangle in file order, with the ray-independent part of ray_triangle
+ * (shader.wgsl:262-264) hoisted: a, ab = b - a, ac = c - a, n = cross(ab, ac),
+ * computed on the host with the same f32 operations the shader uses.
+ *   q0 = (a.x, a.y, a.z, ab.x)  q1 = (ab.y, ab.z, ac.x, ac.y)  q2 = (ac.z, n.x, n.y, n.z) */
+struct PTTriRecord { float4 q[3]; };
+
+/* A pixel whose primary ray hit something; consumed by the path kernel. */
+struct PTHitRecord {
+    uint32_t pixel;     /* y * width + x */
+    int32_t prim_id;    /* triangle index, or -(1+sphere) */
+    float distance;
+    uint32_t pad;
+};
+
+/* control words in device memory, zeroed before each frame */
+struct PTControl {
+    uint32_t hit_count;     /* number of PTHitRecord written by the primary kernel */
+    uint32_t next_item;     /* path-kernel work queue head */
+    uint32_t pad[14];
+};
+
+struct PTKernelParams {
+    uint32_t width, height, rays_per_pixel, max_bounce_count;
+    uint32_t frame_count;
+    uint32_t accum_mode;           /* 0: running mean (shader.wgsl:104-106), 1: add the frame mean */
+    float width_f, height_f, screen_w, screen_h;
+    float cam_pos[3];
+    float cos_a, sin_a, cos_b, sin_b, cos_c, sin_c;
+    float tri_color[3], tri_emission_color[3], tri_emission_strength, tri_smoothness;
+    float sky_horizon[3], sky_zenith[3], ground[3], neg_sun[3], sun_intensity, sun_focus;
+    uint32_t use_env;
+    uint32_t sphere_count;
+    uint32_t root_ref;
+    const PTInnerRecord *inner;
+    const PTTriRecord *tris;
+    const float *spheres;
+    const uint32_t *big_leaf_count;
+    float4 *accum;
+    PTHitRecord *hits;
+    PTControl *ctrl;
+    float4 *samples;
+    int32_t *out_ids;
+    float *out_dist;
+    unsigned long long *counters;  /* 8 words, see flush_counters */
+};
+
+/* launchers implemented in pt_kernels.hip; stack_entries selects the LDS stack size */
+hipError_t pt_launch_primary(const PTKernelParams &kp, int stack_entries, bool exact_math,
+                             bool count_work, bool aov_only, hipStream_t stream);
+hipError_t pt_launch_paths(const PTKernelParams &kp, int stack_entries, bool exact_math,
+                           bool count_work, int num_cus, hipStream_t stream);
+hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t stream);
+hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t stream);
+int pt_max_stack_entries(void);
+
+#endif

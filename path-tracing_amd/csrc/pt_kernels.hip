@@ -1,0 +1,549 @@
+/*
+ * gfx950 kernels of the path-tracing hot path.
+ *
+ * What is computed is fixed by the reference fragment shader
+ * src/shaders/shader.wgsl (function by function citations below); how it is
+ * computed is MI355X-specific:
+ *
+ *   primary_kernel  one lane per pixel, one wave per 8x8 tile.  Every sample of
+ *                   a pixel shares the same primary ray (the shader has no
+ *                   sub-pixel jitter, shader.wgsl:80-101), so the first cast is
+ *                   done once per pixel and frame.  Miss pixels are finished
+ *                   here; hit pixels are appended to a compact list.
+ *   path_kernel     persistent waves; each lane owns one path (pixel, sample)
+ *                   from its first bounce to termination and refills itself from
+ *                   a global queue (wave ballot + one atomic per refill), so
+ *                   lanes stay busy although paths have very different lengths.
+ *                   BVH traversal stacks live in LDS, one column per lane.
+ *   resolve_kernel  per hit pixel: adds the samples in the shader's order and
+ *                   applies the progressive accumulation (shader.wgsl:99-106).
+ *
+ * All arithmetic that decides a hit is plain IEEE binary32 in the shader's
+ * evaluation order with FMA contraction off, so closest-hit ids and distances
+ * are reproducible bit for bit on a CPU.
+ */
+#include "pt_internal.h"
+#include "pt_portable_math.h"
+
+#pragma clang fp contract(off)
+
+#define PT_FAR 1000000.0f          /* shader.wgsl:142,177 */
+#define PT_BOX_MISS 999999999.0f   /* shader.wgsl:254 */
+#define PT_PI 3.14159f             /* shader.wgsl:36,365 */
+#define PT_NONE INT32_MIN
+
+#define PT_WAVES_PER_BLOCK 4
+#define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+/* normalize(v) = v * (1/sqrt(dot(v,v))), correctly rounded / and sqrt */
+__device__ __forceinline__ V3 normalize3(V3 a) {
+    float inv = 1.0f / sqrtf(dot3(a, a));
+    return a * inv;
+}
+__device__ __forceinline__ V3 ld3(const float *p) { return mk(p[0], p[1], p[2]); }
+/* shader.wgsl:385-388 */
+__device__ __forceinline__ V3 lerp3(V3 a, V3 b, float t) { return a * (1.0f - t) + b * t; }
+/* IEEE minNum / maxNum: v_min_f32 / v_max_f32 */
+__device__ __forceinline__ float fmin_(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return __builtin_fmaxf(a, b); }
+
+/* ---- transcendental functions: two interchangeable sets ---- */
+template <bool EXACT> __device__ __forceinline__ float t_log(float x) {
+    if (EXACT) return pm_logf(x);
+    return __builtin_amdgcn_logf(x) * 0.69314718056f;           /* v_log_f32 is log2 */
+}
+template <bool EXACT> __device__ __forceinline__ float t_cos(float x) {
+    if (EXACT) return pm_cosf(x);
+    return __builtin_amdgcn_cosf(x * 0.15915494309f);           /* v_cos_f32 takes revolutions */
+}
+template <bool EXACT> __device__ __forceinline__ float t_pow(float x, float y) {
+    if (EXACT) return pm_powf(x, y);
+    return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+}
+
+struct Counters { unsigned long long casts, boxes, tris, paths; };
+
+/* ---- RNG, shader.wgsl:351-375 ---- */
+__device__ __forceinline__ float random_value(uint32_t state) {
+    state = state ^ (state << 13);
+    state = state ^ (state >> 17);
+    state = state ^ (state << 5);
+    return (float)state / 4294967296.0f;
+}
+template <bool EXACT> __device__ __forceinline__ float random_normal(uint32_t seed) {
+    float u1 = random_value(seed);
+    float u2 = random_value(seed * 7462u);
+    return sqrtf(-2.0f * t_log<EXACT>(u1)) * t_cos<EXACT>(2.0f * PT_PI * u2);
+}
+template <bool EXACT> __device__ __forceinline__ V3 random_direction(uint32_t seed) {
+    float x = random_normal<EXACT>(seed);
+    float y = random_normal<EXACT>(seed * 379u);
+    float z = random_normal<EXACT>(seed * 123u);
+    return normalize3(mk(x, y, z));
+}
+
+/* ---- camera, shader.wgsl:80-95 and 327-348 (trig values come from the host) ---- */
+__device__ __forceinline__ V3 rotate_vector(const PTKernelParams &P, V3 r) {
+    float x = r.x, y = r.y, z = r.z;
+    float cos_a = P.cos_a, sin_a = P.sin_a, cos_b = P.cos_b, sin_b = P.sin_b, cos_c = P.cos_c, sin_c = P.sin_c;
+    float x_rot = x * cos_c * cos_b + y * (cos_c * sin_b * sin_a - sin_c * cos_a) + z * (cos_c * sin_b * cos_a + sin_c * sin_a);
+    float y_rot = x * sin_c * cos_b + y * (sin_c * sin_b * sin_a + cos_c * cos_a) + z * (sin_c * sin_b * cos_a - cos_c * sin_a);
+    float z_rot = -x * sin_b + y * cos_b * sin_a + z * cos_b * cos_a;
+    return mk(x_rot, y_rot, z_rot);
+}
+
+__device__ __forceinline__ void primary_ray(const PTKernelParams &P, uint32_t px, uint32_t py,
+                                            V3 &dir, uint32_t &pixel_index) {
+    float pos_x = (float)px + 0.5f, pos_y = (float)py + 0.5f;
+    float u = (2.0f * pos_x / P.width_f - 1.0f) * P.screen_w / 2.0f;
+    float v = (1.0f - 2.0f * pos_y / P.height_f) * P.screen_h / 2.0f;
+    pixel_index = (uint32_t)(pos_x + pos_y * P.width_f);       /* f32 arithmetic, shader.wgsl:83 */
+    dir = rotate_vector(P, normalize3(mk(u, v, -1.0f)));
+}
+
+/* ---- ray_box, shader.wgsl:237-256 ---- */
+__device__ __forceinline__ float ray_box(V3 o, V3 d, float bminx, float bminy, float bminz,
+                                         float bmaxx, float bmaxy, float bmaxz) {
+    float tminx = (bminx - o.x) / d.x, tminy = (bminy - o.y) / d.y, tminz = (bminz - o.z) / d.z;
+    float tmaxx = (bmaxx - o.x) / d.x, tmaxy = (bmaxy - o.y) / d.y, tmaxz = (bmaxz - o.z) / d.z;
+    float t1x = fmin_(tminx, tmaxx), t1y = fmin_(tminy, tmaxy), t1z = fmin_(tminz, tmaxz);
+    float t2x = fmax_(tminx, tmaxx), t2y = fmax_(tminy, tmaxy), t2z = fmax_(tminz, tmaxz);
+    float t_near = fmax_(fmax_(t1x, t1y), t1z);
+    float t_far = fmin_(fmin_(t2x, t2y), t2z);
+    bool did_hit = (t_near <= t_far) && (t_far >= 0.0f);
+    return did_hit ? t_near : PT_BOX_MISS;
+}
+
+/* ---- ray_triangle distance part, shader.wgsl:258-280 (edges and normal precomputed) ---- */
+__device__ __forceinline__ bool ray_triangle(V3 o, V3 d, const PTTriRecord *t, float &dst_out) {
+    float4 q0 = t->q[0], q1 = t->q[1], q2 = t->q[2];
+    V3 a = mk(q0.x, q0.y, q0.z), edge_ab = mk(q0.w, q1.x, q1.y), edge_ac = mk(q1.z, q1.w, q2.x);
+    V3 normal_vector = mk(q2.y, q2.z, q2.w);
+    float determinant = -dot3(d, normal_vector);
+    if (!(determinant >= 0.0001f)) return false;      /* did_hit needs it (shader.wgsl:279); nothing else is kept on a miss */
+    V3 ao = o - a;
+    V3 dao = cross3(ao, d);
+    float inv_det = 1.0f / determinant;
+    float dst = dot3(ao, normal_vector) * inv_det;
+    float u = dot3(edge_ac, dao) * inv_det;
+    float v = -dot3(edge_ab, dao) * inv_det;
+    float w = 1.0f - u - v;
+    dst_out = dst;
+    return dst >= 0.0f && u >= 0.0f && v >= 0.0f && w >= 0.0f;
+}
+
+/* ---- ray_sphere distance part, shader.wgsl:292-315 ---- */
+__device__ __forceinline__ bool ray_sphere(V3 o, V3 d, const float *s, float &dst_out) {
+    V3 oc = o - ld3(s);
+    float radius = s[3];
+    float a = dot3(d, d);
+    float b = 2.0f * dot3(oc, d);
+    float c = dot3(oc, oc) - radius * radius;
+    float discriminant = b * b - 4.0f * a * c;
+    if (discriminant >= 0.0f) {
+        float distance = (-b - sqrtf(discriminant)) / (2.0f * a);
+        if (distance >= 0.0f) { dst_out = distance; return true; }
+    }
+    return false;
+}
+
+/*
+ * ray_triangle_bvh, shader.wgsl:169-235, on the repacked records.  Visit order,
+ * near/far rule (`dst_a < dst_b` else b is near), strict `<` pruning against the
+ * running best and "no re-test when a pushed node is popped" are the shader's.
+ * The near child is kept in a register instead of being pushed and popped
+ * again; that is the same order.  stk points at this lane's column of the LDS
+ * stack (entries 64 dwords apart, so a wave's accesses never bank-conflict).
+ */
+template <bool COUNT>
+__device__ __forceinline__ void bvh_closest(const PTKernelParams &P, V3 o, V3 d, uint32_t *stk,
+                                            float &best_t, int32_t &best_id, Counters &cn) {
+    best_t = PT_FAR;
+    best_id = PT_NONE;
+    uint32_t cur = P.root_ref;
+    int sp = 0;
+    bool have = true;
+    for (;;) {
+        if (!have) {
+            if (sp == 0) break;
+            sp--;
+            cur = stk[sp * 64];
+        }
+        have = false;
+        if (cur & PT_REF_LEAF) {
+            uint32_t first = cur & 0x00ffffffu;
+            uint32_t cnt = (cur >> 24) & 0x7fu;
+            if (cnt == PT_REF_COUNT_ESCAPE) cnt = P.big_leaf_count[first];
+            for (uint32_t i = first; i < first + cnt; i++) {
+                float dst;
+                bool hit = ray_triangle(o, d, P.tris + i, dst);
+                if (COUNT) cn.tris++;
+                if (hit && dst < best_t) { best_t = dst; best_id = (int32_t)i; }
+            }
+        } else {
+            const PTInnerRecord *rec = P.inner + cur;
+            float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
+            float dst_a = ray_box(o, d, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
+            float dst_b = ray_box(o, d, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
+            if (COUNT) cn.boxes += 2;
+            uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+            float dst_near, dst_far;
+            uint32_t ref_near, ref_far;
+            if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
+            else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
+            if (dst_far < best_t) { stk[sp * 64] = ref_far; sp++; }
+            if (dst_near < best_t) { cur = ref_near; have = true; }
+        }
+    }
+}
+
+/* calculate_ray_collision, shader.wgsl:139-163: spheres in index order, then the
+ * BVH (which does not see the sphere distance), strict `<` everywhere. */
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const PTKernelParams &P, V3 o, V3 d, uint32_t *stk,
+                                            float &t_out, int32_t &id_out, Counters &cn) {
+    float best = PT_FAR;
+    int32_t id = PT_NONE;
+    for (uint32_t k = 0; k < P.sphere_count; k++) {
+        float dst;
+        if (ray_sphere(o, d, P.spheres + 12 * k, dst) && dst < best) { best = dst; id = -(int32_t)(1 + k); }
+    }
+    float bt; int32_t bid;
+    bvh_closest<COUNT>(P, o, d, stk, bt, bid, cn);
+    if (bid != PT_NONE && bt < best) { best = bt; id = bid; }
+    if (COUNT) cn.casts++;
+    t_out = best;
+    id_out = id;
+}
+
+struct Surface { V3 position, normal, color, emission_color; float emission_strength, smoothness; };
+
+/* the HitInfo fields of the winning primitive (shader.wgsl:280-286, 313-320) */
+__device__ __forceinline__ Surface surface_of(const PTKernelParams &P, V3 o, V3 d, float t, int32_t id) {
+    Surface s;
+    s.position = o + d * t;
+    if (id >= 0) {
+        const PTTriRecord *tr = P.tris + id;
+        float4 q2 = tr->q[2];
+        s.normal = normalize3(mk(q2.y, q2.z, q2.w));
+        s.color = ld3(P.tri_color);
+        s.emission_color = ld3(P.tri_emission_color);
+        s.emission_strength = P.tri_emission_strength;
+        s.smoothness = P.tri_smoothness;
+    } else {
+        const float *sp = P.spheres + 12 * (uint32_t)(-(id + 1));
+        s.normal = normalize3(s.position - ld3(sp));
+        s.color = ld3(sp + 4);
+        s.emission_color = ld3(sp + 7);
+        s.emission_strength = sp[10];
+        s.smoothness = sp[11];
+    }
+    return s;
+}
+
+__device__ __forceinline__ float smoothstep_(float e0, float e1, float x) {
+    float t = (x - e0) / (e1 - e0);
+    t = fmin_(fmax_(t, 0.0f), 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+
+/* get_environment_light, shader.wgsl:391-404 (neg_sun = -normalize(sun_light_direction)) */
+template <bool EXACT>
+__device__ __forceinline__ V3 environment_light(const PTKernelParams &P, V3 dir) {
+    float sky_gradient_t = t_pow<EXACT>(smoothstep_(0.0f, 0.4f, dir.y), 0.35f);
+    V3 sky_gradient = lerp3(ld3(P.sky_horizon), ld3(P.sky_zenith), sky_gradient_t);
+    float sun = t_pow<EXACT>(fmax_(0.0f, dot3(dir, ld3(P.neg_sun))), P.sun_focus) * P.sun_intensity;
+    float ground_to_sky_t = smoothstep_(-0.01f, 0.0f, dir.y);
+    float sun_mask = (ground_to_sky_t >= 1.0f) ? 1.0f : 0.0f;
+    V3 r = lerp3(ld3(P.ground), sky_gradient, ground_to_sky_t);
+    float ss = sun * sun_mask;
+    return mk(r.x + ss, r.y + ss, r.z + ss);
+}
+
+/* one "hit" iteration of trace, shader.wgsl:119-127 */
+template <bool EXACT>
+__device__ __forceinline__ void bounce(const PTKernelParams &P, const Surface &s, uint32_t seed, uint32_t i,
+                                       V3 &ro, V3 &rd, V3 &light, V3 &ray_color) {
+    ro = s.position;
+    uint32_t rs = seed + i * 12345u + P.frame_count * 393939123u;
+    V3 diffuse_dir = normalize3(s.normal + random_direction<EXACT>(rs));
+    float dn2 = 2.0f * dot3(s.normal, rd);
+    V3 specular_dir = rd - s.normal * dn2;
+    rd = lerp3(diffuse_dir, specular_dir, s.smoothness);
+    V3 emitted_light = s.emission_color * s.emission_strength;
+    light = light + emitted_light * ray_color;
+    ray_color = ray_color * s.color;
+}
+
+/* the tail of fs_main, shader.wgsl:102-106, or the summing form used by frame-sharded renders */
+__device__ __forceinline__ void accumulate(const PTKernelParams &P, uint32_t pixel, V3 sum) {
+    float n = (float)P.rays_per_pixel;
+    V3 pixel_color = mk(sum.x / n, sum.y / n, sum.z / n);
+    float4 old = P.accum[pixel];
+    float4 out;
+    if (P.accum_mode == 0) {
+        float weight = 1.0f / (float)(P.frame_count + 1u);
+        V3 wa = mk(old.x, old.y, old.z) * (1.0f - weight) + pixel_color * weight;
+        out = make_float4(wa.x, wa.y, wa.z, 0.0f);
+    } else {
+        out = make_float4(old.x + pixel_color.x, old.y + pixel_color.y, old.z + pixel_color.z, 0.0f);
+    }
+    P.accum[pixel] = out;
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+__device__ __forceinline__ uint32_t prefix_count(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+/* counters[0..3] = casts, box tests, triangle tests, paths as the reference would execute them;
+ * counters[4..6] = the share of the first three done by the path kernel */
+__device__ __forceinline__ void flush_counters(const PTKernelParams &P, const Counters &cn, unsigned long long scale,
+                                               bool path_kernel) {
+    unsigned long long c = wave_sum(cn.casts), b = wave_sum(cn.boxes), t = wave_sum(cn.tris), p = wave_sum(cn.paths);
+    if (lane_id() == 0) {
+        atomicAdd(&P.counters[0], c * scale);
+        atomicAdd(&P.counters[1], b * scale);
+        atomicAdd(&P.counters[2], t * scale);
+        atomicAdd(&P.counters[3], p * scale);
+        if (path_kernel) {
+            atomicAdd(&P.counters[4], c);
+            atomicAdd(&P.counters[5], b);
+            atomicAdd(&P.counters[6], t);
+        }
+    }
+}
+
+/* ======================= primary rays ======================= */
+template <int STACK, bool EXACT, bool COUNT, bool AOV>
+__global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
+    __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *stk = &stack[wave][0][lane];
+    /* block = 16x16 pixels, wave = 8x8 tile */
+    const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const bool valid = px < P.width && py < P.height;
+    Counters cn = {0, 0, 0, 0};
+
+    V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
+    uint32_t pixel_index = 0;
+    float t = PT_FAR;
+    int32_t id = PT_NONE;
+    if (valid) {
+        primary_ray(P, px, py, rd, pixel_index);
+        closest_hit<COUNT>(P, ro, rd, stk, t, id, cn);
+    }
+    const uint32_t pixel = py * P.width + px;
+    if (AOV) {
+        if (valid) { P.out_ids[pixel] = id; P.out_dist[pixel] = t; }
+        return;
+    }
+    const bool hit = valid && id != PT_NONE;
+    /* compact the hit pixels of this wave into the global list: one atomic per wave */
+    unsigned long long mask = __ballot(hit);
+    if (mask) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&P.ctrl->hit_count, (uint32_t)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (hit) {
+            PTHitRecord r;
+            r.pixel = pixel; r.prim_id = id; r.distance = t; r.pad = 0;
+            P.hits[base + prefix_count(mask)] = r;
+        }
+    }
+    if (valid && !hit) {
+        /* every sample of the pixel is the same environment lookup (trace breaks at the first cast) */
+        V3 e = mk(0.0f, 0.0f, 0.0f);
+        if (P.use_env) e = environment_light<EXACT>(P, rd) * mk(1.0f, 1.0f, 1.0f);
+        V3 incoming = mk(0.0f, 0.0f, 0.0f) + e;
+        V3 sum = mk(0.0f, 0.0f, 0.0f);
+        for (uint32_t s = 0; s < P.rays_per_pixel; s++) sum = sum + incoming;
+        accumulate(P, pixel, sum);
+    }
+    if (COUNT) {
+        if (valid) cn.paths = 1;
+        flush_counters(P, cn, P.rays_per_pixel, false);   /* the reference repeats the primary cast for every sample */
+    }
+}
+
+/* ======================= bounces ======================= */
+template <int STACK, bool EXACT, bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
+    __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t *stk = &stack[wave][0][lane];
+    const uint32_t rpp = P.rays_per_pixel;
+    const uint32_t total = P.ctrl->hit_count * rpp;
+    Counters cn = {0, 0, 0, 0};
+
+    bool active = false, drained = false;
+    uint32_t item = 0, seed = 0, i = 0;
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
+
+    for (;;) {
+        unsigned long long need = __ballot(!active);
+        if (need && !drained) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&P.ctrl->next_item, (uint32_t)__popcll(need));
+            base = __shfl(base, 0, 64);
+            if (base >= total) drained = true;
+            if (!active) {
+                item = base + prefix_count(need);
+                if (item < total) {
+                    /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
+                    PTHitRecord h = P.hits[item / rpp];
+                    uint32_t s = item % rpp;
+                    uint32_t px = h.pixel % P.width, py = h.pixel / P.width;
+                    uint32_t pixel_index;
+                    primary_ray(P, px, py, rd, pixel_index);
+                    ro = ld3(P.cam_pos);
+                    seed = pixel_index + s * 248135u;                      /* shader.wgsl:100 */
+                    light = mk(0.0f, 0.0f, 0.0f);
+                    ray_color = mk(1.0f, 1.0f, 1.0f);
+                    Surface sf = surface_of(P, ro, rd, h.distance, h.prim_id);
+                    bounce<EXACT>(P, sf, seed, 0u, ro, rd, light, ray_color);
+                    i = 1;
+                    active = true;
+                }
+            }
+        }
+        if (!__ballot(active)) break;
+        if (active) {
+            bool finished;
+            if (i > P.max_bounce_count) {
+                finished = true;                                           /* loop bound reached, no sky term */
+            } else {
+                float t; int32_t id;
+                closest_hit<COUNT>(P, ro, rd, stk, t, id, cn);
+                if (id != PT_NONE) {
+                    Surface sf = surface_of(P, ro, rd, t, id);
+                    bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
+                    i++;
+                    finished = i > P.max_bounce_count;
+                } else {
+                    if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
+                    finished = true;
+                }
+            }
+            if (finished) {
+                P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
+                active = false;
+            }
+        }
+    }
+    if (COUNT) flush_counters(P, cn, 1ull, true);
+}
+
+/* ======================= per-pixel resolve ======================= */
+__global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= P.ctrl->hit_count) return;
+    const uint32_t pixel = P.hits[h].pixel;
+    const float4 *s = P.samples + (size_t)h * P.rays_per_pixel;
+    V3 sum = mk(0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < P.rays_per_pixel; k++) {          /* shader.wgsl:99-101, in sample order */
+        float4 v = s[k];
+        sum = sum + mk(v.x, v.y, v.z);
+    }
+    accumulate(P, pixel, sum);
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, float s) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 v = accum[i];
+    accum[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w);
+}
+
+/* ======================= launchers ======================= */
+static const int kStackSizes[] = {24, 32, 48, 64};
+int pt_max_stack_entries(void) { return 64; }
+
+template <int STACK>
+static hipError_t launch_primary_s(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
+    dim3 grid((kp.width + 15) / 16, (kp.height + 15) / 16), block(PT_BLOCK);
+    if (aov) {
+        hipLaunchKernelGGL((primary_kernel<STACK, true, false, true>), grid, block, 0, st, kp);
+    } else if (count) {
+        if (exact) hipLaunchKernelGGL((primary_kernel<STACK, true, true, false>), grid, block, 0, st, kp);
+        else       hipLaunchKernelGGL((primary_kernel<STACK, false, true, false>), grid, block, 0, st, kp);
+    } else {
+        if (exact) hipLaunchKernelGGL((primary_kernel<STACK, true, false, false>), grid, block, 0, st, kp);
+        else       hipLaunchKernelGGL((primary_kernel<STACK, false, false, false>), grid, block, 0, st, kp);
+    }
+    return hipGetLastError();
+}
+
+template <int STACK>
+static hipError_t launch_paths_s(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
+    /* persistent grid: enough blocks to fill every CU for the LDS the stack needs */
+    size_t lds = (size_t)PT_WAVES_PER_BLOCK * STACK * 64 * 4;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    dim3 grid(num_cus * per_cu), block(PT_BLOCK);
+    if (count) {
+        if (exact) hipLaunchKernelGGL((path_kernel<STACK, true, true>), grid, block, 0, st, kp);
+        else       hipLaunchKernelGGL((path_kernel<STACK, false, true>), grid, block, 0, st, kp);
+    } else {
+        if (exact) hipLaunchKernelGGL((path_kernel<STACK, true, false>), grid, block, 0, st, kp);
+        else       hipLaunchKernelGGL((path_kernel<STACK, false, false>), grid, block, 0, st, kp);
+    }
+    return hipGetLastError();
+}
+
+static int pick_stack(int need) {
+    for (int s : kStackSizes) if (need <= s) return s;
+    return -1;
+}
+
+hipError_t pt_launch_primary(const PTKernelParams &kp, int stack_entries, bool exact, bool count,
+                             bool aov, hipStream_t st) {
+    switch (pick_stack(stack_entries)) {
+        case 24: return launch_primary_s<24>(kp, exact, count, aov, st);
+        case 32: return launch_primary_s<32>(kp, exact, count, aov, st);
+        case 48: return launch_primary_s<48>(kp, exact, count, aov, st);
+        case 64: return launch_primary_s<64>(kp, exact, count, aov, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t pt_launch_paths(const PTKernelParams &kp, int stack_entries, bool exact, bool count,
+                           int num_cus, hipStream_t st) {
+    switch (pick_stack(stack_entries)) {
+        case 24: return launch_paths_s<24>(kp, exact, count, num_cus, st);
+        case 32: return launch_paths_s<32>(kp, exact, count, num_cus, st);
+        case 48: return launch_paths_s<48>(kp, exact, count, num_cus, st);
+        case 64: return launch_paths_s<64>(kp, exact, count, num_cus, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t st) {
+    uint32_t n = kp.width * kp.height;   /* upper bound of the hit list; surplus threads exit */
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kp);
+    return hipGetLastError();
+}
+
+hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t st) {
+    hipLaunchKernelGGL(scale_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, st, accum, n_pixels, s);
+    return hipGetLastError();
+}

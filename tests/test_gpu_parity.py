@@ -1,0 +1,193 @@
+"""HIP path vs CPU oracle, through the C ABI (libpt_hip.so).  All tests need an MI355X.
+
+Bars:
+  - primary-ray closest-hit ids and distances: bit-exact;
+  - radiance in exact-math mode (portable polynomial log/cos/pow on both sides): bit-exact;
+  - radiance in the default mode (hardware v_log/v_cos/v_exp vs libm): per-pixel tolerance
+    stated in each test;
+  - work counters in exact-math mode: equal integers.
+"""
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pkg, scenes, oracle, n, flags=0, **over):
+    cfg = scenes.config(n, **over)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    spheres = scenes.spheres_for(cfg["spheres"])
+    params = pkg.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=cfg["rays_per_pixel"],
+                                max_bounce_count=cfg["max_bounce_count"], flags=flags)
+    r = pkg.Renderer(params, device=0)
+    r.upload_scene(spheres, tris, bvh)
+    r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+    op = oracle.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=cfg["rays_per_pixel"],
+                               max_bounce_count=cfg["max_bounce_count"])
+    sc = oracle.scene(spheres, tris, bvh)
+    return cfg, r, op, sc
+
+
+@pytest.mark.parametrize("n,w,h", [(1, 640, 360), (2, 480, 270), (3, 480, 270), (5, 480, 270)])
+def test_primary_hits_bit_exact(pkg, scenes, oracle, n, w, h):
+    cfg, r, op, sc = _setup(pkg, scenes, oracle, n, width=w, height=h, rays_per_pixel=1)
+    with r:
+        ids, dist = r.primary_hits()
+    oids, odist = oracle.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
+    assert (ids != pkg.MISS_ID).mean() > 0.05
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(bits(dist), bits(odist))
+
+
+def test_primary_hits_bit_exact_full_1080p_dragon8k(pkg, scenes, oracle):
+    """BASELINE config 2 at its full resolution (2 M primary rays, legacy depth-21 BVH)."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle, 2, rays_per_pixel=1)
+    with r:
+        ids, dist = r.primary_hits()
+    oids, odist = oracle.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(bits(dist), bits(odist))
+
+
+def test_primary_hits_odd_size_and_rotated_camera(pkg, scenes, oracle):
+    """Width/height that are not multiples of the 16x16 block, all three rotation angles non-zero."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle, 1, width=203, height=117, rays_per_pixel=1,
+                            camera_position=(60.0, 90.0, 140.0), camera_rotation=(-25.0, 20.0, 10.0))
+    with r:
+        ids, dist = r.primary_hits()
+    oids, odist = oracle.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
+    assert (ids != pkg.MISS_ID).mean() > 0.05
+    assert np.array_equal(ids, oids)
+    assert np.array_equal(bits(dist), bits(odist))
+
+
+@pytest.mark.parametrize("n,w,h,rpp,frames", [(1, 160, 90, 3, 2), (2, 128, 72, 4, 2), (5, 128, 72, 2, 3), (3, 96, 54, 2, 1)])
+def test_radiance_exact_math_bit_exact(pkg, scenes, oracle_shared, n, w, h, rpp, frames):
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, n, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=w, height=h, rays_per_pixel=rpp)
+    with r:
+        r.render(frames)
+        img = r.read_accum(4)
+        assert r.frame_count == frames
+    oimg = oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, frames)
+    assert np.array_equal(bits(img[..., :3]), bits(oimg[..., :3]))
+
+
+def test_counters_match_oracle_in_exact_mode(pkg, scenes, oracle_shared, orc_mod):
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH | pkg.PT_FLAG_COUNT_WORK,
+                            width=160, height=90, rays_per_pixel=2)
+    with r:
+        r.render(2)
+        got = r.counters()
+    c = orc_mod.OrcCounters()
+    oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 2, counters=c)
+    want = c.as_dict()
+    assert got["ray_casts"] == want["ray_casts"]
+    assert got["box_tests"] == want["box_tests"]
+    assert got["tri_tests"] == want["tri_tests"]
+    assert got["paths"] == want["paths"]
+
+
+def test_radiance_default_math_within_tolerance(pkg, scenes, oracle):
+    """Hardware transcendentals vs libm: paths may diverge on a few pixels (a 1-ulp change of a
+    bounce direction can flip a hit near an edge).  Tolerance: 99 % of pixels within 2e-3 relative
+    (+1e-4 absolute) and image-mean relative error below 2e-3."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle, 1, width=160, height=90, rays_per_pixel=4)
+    with r:
+        r.render(2)
+        img = r.read_accum(4)[..., :3]
+    oimg = oracle.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 2)[..., :3]
+    err = np.abs(img - oimg)
+    ok = err <= 2e-3 * np.abs(oimg) + 1e-4
+    assert ok.all(axis=-1).mean() > 0.99
+    assert abs(img.mean() - oimg.mean()) <= 2e-3 * oimg.mean()
+
+
+def test_running_mean_resumes_and_frame0_overwrites(pkg, scenes, oracle_shared):
+    """frames 0..2 in one call == frames 0, then 1..2 in two calls; frame_count 0 ignores old contents."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=2)
+    with r:
+        r.render_frames(0, 3)
+        a = r.read_accum(4)
+        r.render_frames(0, 1)      # overwrites (weight 1)
+        r.render_frames(1, 2)
+        b = r.read_accum(4)
+    assert np.array_equal(bits(a), bits(b))
+
+
+def test_sum_mode_matches_oracle_and_sharding(pkg, scenes, oracle_shared):
+    """pt_render_frames_sum over 2 'virtual ranks' (frame stride 2) summed on the host equals the
+    oracle's per-rank sums bit for bit; scaled by 1/n it is within 4 ulp-ish (1e-6 rel) of the
+    running mean."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=2)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    with r:
+        parts = []
+        for rank in range(2):
+            r.reset_accum()
+            r.render_frames_sum(rank, 2, 2)
+            parts.append(r.read_accum(4))
+        r.render_frames(0, 4)
+        mean = r.read_accum(4)
+        r.reset_accum()
+        r.render_frames_sum(0, 4, 1)
+        r.scale_accum(0.25)
+        scaled = r.read_accum(4)
+    for rank in range(2):
+        o = oracle_shared.render_frames_sum(op, sc, cam, rot, rank, 2, 2)
+        assert np.array_equal(bits(parts[rank][..., :3]), bits(o[..., :3]))
+    total = (parts[0] + parts[1]) * np.float32(0.25)
+    np.testing.assert_allclose(total[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(scaled[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)
+
+
+def test_zero_bounces_and_no_spheres(pkg, scenes, oracle_shared):
+    """max_bounce_count = 0 (one cast per sample) and an empty sphere list."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=2, max_bounce_count=0, spheres="none")
+    with r:
+        r.render(1)
+        img = r.read_accum(4)
+    oimg = oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 1)
+    assert np.array_equal(bits(img[..., :3]), bits(oimg[..., :3]))
+
+
+def test_bind_external_accum_buffer(pkg, scenes, oracle_shared):
+    torch = pytest.importorskip("torch")
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=1)
+    with r:
+        buf = torch.zeros(54 * 96 * 4, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        r.bind_accum(buf.data_ptr())
+        r.render(1)
+        r.synchronize()
+        ext = buf.cpu().numpy().reshape(54, 96, 4)
+        r.bind_accum(0)
+        r.render_frames(0, 1)
+        own = r.read_accum(4)
+    assert np.array_equal(bits(ext), bits(own))
+
+
+def test_errors_are_reported_not_fatal(pkg, scenes):
+    params = pkg.default_params(width=64, height=36, rays_per_pixel=1)
+    with pkg.Renderer(params, device=0) as r:
+        with pytest.raises(pkg.PtError):
+            r.render(1)                                   # no scene
+        bad = np.zeros((3, 9), np.float32)
+        bad[0, 8] = 7.0                                   # child link outside the array
+        with pytest.raises(pkg.PtError):
+            r.upload_scene(np.zeros((0, 12), np.float32), np.zeros((1, 9), np.float32), bad)
+        cyc = np.zeros((3, 9), np.float32)
+        cyc[0, 8] = 1.0
+        cyc[1, 8] = 1.0                                   # node 1 is its own child
+        with pytest.raises(pkg.PtError):
+            r.upload_scene(np.zeros((0, 12), np.float32), np.zeros((1, 9), np.float32), cyc)
+    with pytest.raises(pkg.PtError):
+        pkg.Renderer(pkg.default_params(width=0, height=10), device=0)
+    with pytest.raises(pkg.PtError):
+        pkg.Renderer(params, device=99)

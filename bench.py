@@ -188,7 +188,7 @@ def main():
         cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail)), 16))
         op = oracle.default_params(width=W, height=H, rays_per_pixel=rpp, max_bounce_count=cfg["max_bounce_count"])
         sc = oracle.scene(spheres, tris, bvh)
-        cpu_frames = min(n_frames, 2)
+        cpu_frames = min(n_frames, 8)      # ~10-20 s of CPU work on 16 cores
         acc = np.zeros((H, W, 4), np.float32)
         t0 = time.perf_counter()
         oracle.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, cpu_frames,

@@ -1,0 +1,86 @@
+"""Frame sharding across ranks (path-tracing_amd/distributed.py) on CPU: two `gloo` processes, each
+rendering its share of the frames with the CPU oracle standing in for the GPU renderer, one
+all-reduce, scale by 1/n.  Checks the host logic that bench.py --gpus N runs with RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = np.float32
+
+
+def test_shard_frames_partitions_every_frame_once(pkg):
+    from path_tracing_amd.distributed import shard_frames
+    for n_frames in [1, 2, 3, 4, 7, 16, 64]:
+        for world in [1, 2, 3, 4, 8]:
+            seen = []
+            for rank in range(world):
+                first, count, stride = shard_frames(10, n_frames, rank, world)
+                seen += [first + k * stride for k in range(count)]
+            assert sorted(seen) == list(range(10, 10 + n_frames))
+    with pytest.raises(ValueError):
+        shard_frames(0, 4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import render_sharded
+    oracle = entry.load_oracle_module().Oracle(shared_math=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    buf = torch.zeros(27, 48, 4, dtype=torch.float32)
+    arr = buf.numpy()
+
+    def render_sum(first, count, stride):
+        oracle.render_frames_sum(p, sc, cfg["camera_position"], cfg["camera_rotation"], first, count, stride,
+                                 accum=arr, nthreads=2)
+
+    def scale(s):
+        buf.mul_(s)
+
+    render_sharded(render_sum, lambda: dist.all_reduce(buf), scale, 0, n_frames, rank, world)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), arr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [4, 3])
+def test_two_rank_sharded_render_matches_single_rank(tmp_path, oracle_shared, scenes, n_frames):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)                                   # all-reduce: every rank holds the image
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    # exact expectation: (sum over rank-0 frames) + (sum over rank-1 frames), times 1/n, all in f32
+    parts = [oracle_shared.render_frames_sum(p, sc, cam, rot, rank, len(range(rank, n_frames, 2)), 2) for rank in range(2)]
+    want = (parts[0] + parts[1]) * F(1.0 / n_frames)
+    assert np.array_equal(r0.view(np.uint32), want.view(np.uint32))
+    # and it is the single-GPU running mean up to f32 rounding (tolerance: 2e-6 relative)
+    mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
+    np.testing.assert_allclose(r0[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)

@@ -172,6 +172,11 @@ int pt_synchronize(pt_ctx *ctx);
 
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);  /* synchronises; needs PT_FLAG_COUNT_WORK */
 int pt_reset_counters(pt_ctx *ctx);
+/* Diagnostics of the path kernel (PT_FLAG_COUNT_WORK), summed over waves: [0] wave lifetime in
+ * shader clocks, [1] clocks inside the traversal loop, [2] traversal steps, [3] lanes at inner
+ * nodes summed over steps, [4] lanes whose leaf code ran, [5] steps in which leaf code ran,
+ * [6] outer iterations, [7] lanes shaded summed over outer iterations.  No reference counterpart. */
+int pt_get_debug_stats(pt_ctx *ctx, uint64_t out[8]);
 int pt_get_timing(pt_ctx *ctx, pt_timing *out);      /* synchronises */
 int pt_reset_timing(pt_ctx *ctx);
 

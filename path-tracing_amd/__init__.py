@@ -61,7 +61,7 @@ API_SYMBOLS = [
     "pt_default_params", "pt_create", "pt_upload_scene", "pt_load_scene_files", "pt_set_camera",
     "pt_render_frames", "pt_render_frames_sum", "pt_scale_accum", "pt_read_accum", "pt_reset_accum",
     "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
-    "pt_reset_counters", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
+    "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
 ]
 
@@ -111,6 +111,7 @@ def load_library():
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_get_counters.argtypes = [C.c_void_p, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [C.c_void_p]
+    L.pt_get_debug_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.pt_get_timing.argtypes = [C.c_void_p, C.POINTER(PtTiming)]
     L.pt_reset_timing.argtypes = [C.c_void_p]
     L.pt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -273,6 +274,13 @@ class Renderer:
         c = PtCounters()
         self._check(self._L.pt_get_counters(self._ctx, C.byref(c)))
         return c.as_dict()
+
+    def debug_stats(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self._L.pt_get_debug_stats(self._ctx, out))
+        names = ["wave_clocks", "trav_clocks", "trav_steps", "inner_lanes", "leaf_lanes", "leaf_runs",
+                 "outer_iters", "shade_lanes"]
+        return dict(zip(names, [int(x) for x in out]))
 
     def reset_counters(self):
         self._check(self._L.pt_reset_counters(self._ctx))

@@ -8,6 +8,7 @@
  */
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
+#include "pt_exact_div.h"
 
 #include <cmath>
 #include <cstdio>
@@ -49,6 +50,9 @@ struct pt_ctx {
     uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
+    bool fast_div = false;
+    uint32_t refill_min = 48;
+    uint32_t leaf_min = 8;
 
     std::vector<EventPair> pending;    /* recorded, not yet read */
     std::vector<EventPair> free_events;
@@ -83,6 +87,7 @@ struct Repacked {
     std::vector<PTInnerRecord> inner;
     std::vector<uint32_t> big;     /* per-triangle count table, only when a leaf has >= 127 triangles */
     uint32_t root_ref = 0, depth = 0, leaves = 0;
+    bool tame_bounds = true;       /* see pt_exact_div.h */
 };
 
 bool finite_nonneg_int(float f) { return f >= 0.0f && f <= 16777216.0f && f == std::floor(f); }
@@ -176,9 +181,11 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
         uint32_t ha = leaf_a ? 0 : height[f.a];
         uint32_t hb = leaf_b ? 0 : height[f.b];
         PTInnerRecord &r = out.inner[f.rec];
-        r.q[0] = make_float4(na[0], na[1], na[2], na[3]);
-        r.q[1] = make_float4(na[4], na[5], nb[0], nb[1]);
-        r.q[2] = make_float4(nb[2], nb[3], nb[4], nb[5]);
+        r.q[0] = make_float4(na[0], nb[0], na[1], nb[1]);
+        r.q[1] = make_float4(na[2], nb[2], na[3], nb[3]);
+        r.q[2] = make_float4(na[4], nb[4], na[5], nb[5]);
+        for (int k = 0; k < 6; k++)
+            if (!pt_div_tame_coordinate(na[k]) || !pt_div_tame_coordinate(nb[k])) out.tame_bounds = false;
         float fa, fb;
         memcpy(&fa, &ra, 4); memcpy(&fb, &rb, 4);
         r.q[3] = make_float4(fa, fb, 0.0f, 0.0f);
@@ -257,6 +264,9 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_count, uint32_t accum_mo
     k.use_env = p.use_environment_lighting ? 1u : 0u;
     k.sphere_count = c->sphere_count;
     k.root_ref = c->root_ref;
+    k.fast_div = c->fast_div ? 1u : 0u;
+    k.refill_min = c->refill_min;
+    k.leaf_min = c->leaf_min;
     k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
     k.out_ids = c->d_ids; k.out_dist = c->d_dist; k.counters = c->d_counters;
@@ -364,6 +374,8 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (!c) return fail(nullptr, PT_ENOMEM, "out of host memory");
     c->device = device_ordinal;
     c->params = *params;
+    if (const char *e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_min = (uint32_t)v; }
+    if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }
     auto bail = [&](hipError_t he, const char *what) {
         int r = fail_hip(nullptr, he, what);
         pt_destroy(c);
@@ -383,8 +395,8 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
     if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
     if ((e = hipMalloc(&c->d_samples, npix * params->rays_per_pixel * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(samples)");
-    if ((e = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
     return PT_OK;
@@ -429,6 +441,7 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     c->root_ref = rp.root_ref; c->depth = rp.depth;
     c->inner_count = (uint32_t)rp.inner.size(); c->leaf_count = rp.leaves;
     c->stack_entries = need;
+    c->fast_div = rp.tame_bounds && getenv("PT_NO_FAST_DIV") == nullptr;
     c->scene_loaded = true;
     return PT_OK;
 }
@@ -546,10 +559,22 @@ int pt_get_counters(pt_ctx *c, pt_counters *out) {
     return PT_OK;
 }
 
+int pt_get_debug_stats(pt_ctx *c, uint64_t out[8]) {
+    if (!c) return PT_EINVAL;
+    if (!out) return fail(c, PT_EINVAL, "out is NULL");
+    if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long h[16];
+    HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = h[8 + i];
+    return PT_OK;
+}
+
 int pt_reset_counters(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
     return PT_OK;
 }
 

@@ -17,10 +17,11 @@
  * holds everything a visit needs: both child boxes and both child references.
  * (The reference reads the two 36-byte child nodes, 72 bytes at 36-byte
  * stride, and then re-reads a child when it is popped.)
- *   q0 = (A.min.x, A.min.y, A.min.z, A.max.x)
- *   q1 = (A.max.y, A.max.z, B.min.x, B.min.y)
- *   q2 = (B.min.z, B.max.x, B.max.y, B.max.z)
+ *   q0 = (A.min.x, B.min.x, A.min.y, B.min.y)
+ *   q1 = (A.min.z, B.min.z, A.max.x, B.max.x)
+ *   q2 = (A.max.y, B.max.y, A.max.z, B.max.z)
  *   q3 = (refA, refB, 0, 0) as raw bits
+ * (A and B interleaved so that both boxes are tested with packed-f32 instructions)
  * Box values are copied verbatim from the file, so ray_box sees the same
  * operands as the shader. */
 struct PTInnerRecord { float4 q[4]; };
@@ -58,6 +59,9 @@ struct PTKernelParams {
     uint32_t use_env;
     uint32_t sphere_count;
     uint32_t root_ref;
+    uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */
+    uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
+    uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;
     const PTTriRecord *tris;
     const float *spheres;

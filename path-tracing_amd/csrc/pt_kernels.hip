@@ -24,6 +24,7 @@
  */
 #include "pt_internal.h"
 #include "pt_portable_math.h"
+#include "pt_exact_div.h"
 
 #pragma clang fp contract(off)
 
@@ -111,17 +112,56 @@ __device__ __forceinline__ void primary_ray(const PTKernelParams &P, uint32_t px
     dir = rotate_vector(P, normalize3(mk(u, v, -1.0f)));
 }
 
-/* ---- ray_box, shader.wgsl:237-256 ---- */
-__device__ __forceinline__ float ray_box(V3 o, V3 d, float bminx, float bminy, float bminz,
-                                         float bmaxx, float bmaxy, float bmaxz) {
-    float tminx = (bminx - o.x) / d.x, tminy = (bminy - o.y) / d.y, tminz = (bminz - o.z) / d.z;
-    float tmaxx = (bmaxx - o.x) / d.x, tmaxy = (bmaxy - o.y) / d.y, tmaxz = (bmaxz - o.z) / d.z;
+/* ---- ray_box, shader.wgsl:237-256, for BOTH children of an inner node at once ----
+ * The two boxes ride in the two halves of packed-f32 instructions (v_pk_add_f32,
+ * v_pk_mul_f32, v_pk_fma_f32), which is why the record stores them interleaved.
+ * FAST selects how the quotients are formed: the plain correctly rounded
+ * division, or pt_div_by_reciprocal's multiply + four FMAs with y = 1/d
+ * precomputed per ray (same bits).  The caller picks FAST only for rays and
+ * scenes that satisfy the predicates in pt_exact_div.h. */
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+
+template <bool FAST>
+__device__ __forceinline__ f2 div2(f2 n, float b, float y) {
+    if (FAST) {
+        f2 bb = mk2(b, b), yy = mk2(y, y);
+        f2 q = n * yy;
+        f2 r = __builtin_elementwise_fma(-bb, q, n);
+        q = __builtin_elementwise_fma(r, yy, q);
+        r = __builtin_elementwise_fma(-bb, q, n);
+        return __builtin_elementwise_fma(r, yy, q);
+    }
+    return mk2(n.x / b, n.y / b);
+}
+
+__device__ __forceinline__ float box_result(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz) {
     float t1x = fmin_(tminx, tmaxx), t1y = fmin_(tminy, tmaxy), t1z = fmin_(tminz, tmaxz);
     float t2x = fmax_(tminx, tmaxx), t2y = fmax_(tminy, tmaxy), t2z = fmax_(tminz, tmaxz);
     float t_near = fmax_(fmax_(t1x, t1y), t1z);
     float t_far = fmin_(fmin_(t2x, t2y), t2z);
     bool did_hit = (t_near <= t_far) && (t_far >= 0.0f);
     return did_hit ? t_near : PT_BOX_MISS;
+}
+
+/* q0 = (A.min.x, B.min.x, A.min.y, B.min.y)  q1 = (A.min.z, B.min.z, A.max.x, B.max.x)
+ * q2 = (A.max.y, B.max.y, A.max.z, B.max.z) */
+template <bool FAST>
+__device__ __forceinline__ void ray_box2(V3 o, V3 d, V3 y, float4 q0, float4 q1, float4 q2, float &dst_a, float &dst_b) {
+    f2 tminx = div2<FAST>(mk2(q0.x, q0.y) - mk2(o.x, o.x), d.x, y.x);
+    f2 tminy = div2<FAST>(mk2(q0.z, q0.w) - mk2(o.y, o.y), d.y, y.y);
+    f2 tminz = div2<FAST>(mk2(q1.x, q1.y) - mk2(o.z, o.z), d.z, y.z);
+    f2 tmaxx = div2<FAST>(mk2(q1.z, q1.w) - mk2(o.x, o.x), d.x, y.x);
+    f2 tmaxy = div2<FAST>(mk2(q2.x, q2.y) - mk2(o.y, o.y), d.y, y.y);
+    f2 tmaxz = div2<FAST>(mk2(q2.z, q2.w) - mk2(o.z, o.z), d.z, y.z);
+    dst_a = box_result(tminx.x, tminy.x, tminz.x, tmaxx.x, tmaxy.x, tmaxz.x);
+    dst_b = box_result(tminx.y, tminy.y, tminz.y, tmaxx.y, tmaxy.y, tmaxz.y);
+}
+
+/* may this lane's ray use the reciprocal form?  (scene-side condition: P.fast_div) */
+__device__ __forceinline__ bool ray_div_safe(V3 o, V3 d) {
+    return pt_div_safe_denominator(d.x) && pt_div_safe_denominator(d.y) && pt_div_safe_denominator(d.z) &&
+           pt_div_tame_coordinate(o.x) && pt_div_tame_coordinate(o.y) && pt_div_tame_coordinate(o.z);
 }
 
 /* ---- ray_triangle distance part, shader.wgsl:258-280 (edges and normal precomputed) ---- */
@@ -158,70 +198,141 @@ __device__ __forceinline__ bool ray_sphere(V3 o, V3 d, const float *s, float &ds
 }
 
 /*
- * ray_triangle_bvh, shader.wgsl:169-235, on the repacked records.  Visit order,
- * near/far rule (`dst_a < dst_b` else b is near), strict `<` pruning against the
- * running best and "no re-test when a pushed node is popped" are the shader's.
- * The near child is kept in a register instead of being pushed and popped
- * again; that is the same order.  stk points at this lane's column of the LDS
- * stack (entries 64 dwords apart, so a wave's accesses never bank-conflict).
+ * ray_triangle_bvh, shader.wgsl:169-235, on the repacked records, as a resumable
+ * state machine: trav_step() visits exactly one node.  Visit order, near/far
+ * rule (`dst_a < dst_b` else b is near), strict `<` pruning against the running
+ * best and "no re-test when a pushed node is popped" are the shader's.  The near
+ * child is kept in `cur` instead of being pushed and popped again; that is the
+ * same order.  stk points at this lane's column of the LDS stack (entries 64
+ * dwords apart, so a wave's accesses never bank-conflict).
  */
-template <bool COUNT>
-__device__ __forceinline__ void bvh_closest(const PTKernelParams &P, V3 o, V3 d, uint32_t *stk,
-                                            float &best_t, int32_t &best_id, Counters &cn) {
-    best_t = PT_FAR;
-    best_id = PT_NONE;
-    uint32_t cur = P.root_ref;
-    int sp = 0;
-    bool have = true;
-    for (;;) {
-        if (!have) {
-            if (sp == 0) break;
-            sp--;
-            cur = stk[sp * 64];
-        }
-        have = false;
-        if (cur & PT_REF_LEAF) {
-            uint32_t first = cur & 0x00ffffffu;
-            uint32_t cnt = (cur >> 24) & 0x7fu;
-            if (cnt == PT_REF_COUNT_ESCAPE) cnt = P.big_leaf_count[first];
-            for (uint32_t i = first; i < first + cnt; i++) {
-                float dst;
-                bool hit = ray_triangle(o, d, P.tris + i, dst);
-                if (COUNT) cn.tris++;
-                if (hit && dst < best_t) { best_t = dst; best_id = (int32_t)i; }
-            }
-        } else {
-            const PTInnerRecord *rec = P.inner + cur;
-            float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
-            float dst_a = ray_box(o, d, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y);
-            float dst_b = ray_box(o, d, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w);
-            if (COUNT) cn.boxes += 2;
-            uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
-            float dst_near, dst_far;
-            uint32_t ref_near, ref_far;
-            if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
-            else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
-            if (dst_far < best_t) { stk[sp * 64] = ref_far; sp++; }
-            if (dst_near < best_t) { cur = ref_near; have = true; }
-        }
-    }
+#define PT_REF_NONE 0xffffffffu     /* not a valid reference: see the encoding in pt_internal.h */
+
+struct Trav {
+    uint32_t cur;      /* node to visit next, or PT_REF_NONE: pop one */
+    int sp;            /* entries on the LDS stack */
+    float best_t;
+    int32_t best_id;
+    V3 inv;            /* 1/dir, used by the reciprocal form of ray_box */
+};
+
+__device__ __forceinline__ void trav_begin(const PTKernelParams &P, V3 d, Trav &T) {
+    T.cur = P.root_ref;
+    T.sp = 0;
+    T.best_t = PT_FAR;
+    T.best_id = PT_NONE;
+    T.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
 }
 
-/* calculate_ray_collision, shader.wgsl:139-163: spheres in index order, then the
- * BVH (which does not see the sphere distance), strict `<` everywhere. */
+/* after a visit: continue with the near child if one was kept, else pop; true = stack empty */
+__device__ __forceinline__ bool trav_advance(Trav &T, uint32_t *stk) {
+    if (T.cur != PT_REF_NONE) return false;
+    if (T.sp == 0) return true;
+    T.sp--;
+    T.cur = stk[T.sp * 64];
+    return false;
+}
+
+template <bool FAST, bool COUNT>
+__device__ __forceinline__ void inner_visit(const PTKernelParams &P, V3 o, V3 d, Trav &T, uint32_t *stk, Counters &cn) {
+    const PTInnerRecord *rec = P.inner + T.cur;
+    float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
+    float dst_a, dst_b;
+    ray_box2<FAST>(o, d, T.inv, q0, q1, q2, dst_a, dst_b);
+    if (COUNT) cn.boxes += 2;
+    uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+    float dst_near, dst_far;
+    uint32_t ref_near, ref_far;
+    if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
+    else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
+    if (dst_far < T.best_t) { stk[T.sp * 64] = ref_far; T.sp++; }
+    T.cur = (dst_near < T.best_t) ? ref_near : PT_REF_NONE;
+}
+
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const PTKernelParams &P, V3 o, V3 d, uint32_t *stk,
-                                            float &t_out, int32_t &id_out, Counters &cn) {
-    float best = PT_FAR;
-    int32_t id = PT_NONE;
+__device__ __forceinline__ void leaf_visit(const PTKernelParams &P, V3 o, V3 d, Trav &T, Counters &cn) {
+    uint32_t first = T.cur & 0x00ffffffu;
+    uint32_t cnt = (T.cur >> 24) & 0x7fu;
+    if (cnt == PT_REF_COUNT_ESCAPE) cnt = P.big_leaf_count[first];
+    for (uint32_t i = first; i < first + cnt; i++) {
+        float dst;
+        bool hit = ray_triangle(o, d, P.tris + i, dst);
+        if (COUNT) cn.tris++;
+        if (hit && dst < T.best_t) { T.best_t = dst; T.best_id = (int32_t)i; }
+    }
+    T.cur = PT_REF_NONE;
+}
+
+/*
+ * One step of a whole wave.  Lanes with `traversing` set hold a valid T.cur.  Lanes at an
+ * inner node always advance; lanes at a leaf advance only when at least P.leaf_min lanes of
+ * the wave are at a leaf or no lane has inner work, otherwise they wait one step with their
+ * state untouched.  Waiting changes nothing a lane computes (its own visit order is the
+ * shader's); it keeps the triangle code from running for one or two lanes in every step.
+ * Returns true for lanes whose traversal completed in this step.
+ */
+struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs; };
+
+template <bool FAST, bool COUNT>
+__device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, bool traversing, V3 o, V3 d, Trav &T,
+                                               uint32_t *stk, Counters &cn, WaveStats *ws = nullptr) {
+    const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
+    const bool is_inner = traversing && !is_leaf;
+    const unsigned long long inner_mask = __ballot(is_inner);
+    const unsigned long long leaf_mask = __ballot(is_leaf);
+    bool done = false;
+    if (COUNT && ws) {
+        ws->steps++;
+        ws->inner_lanes += (unsigned)__popcll(inner_mask);
+        if (!inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
+    }
+    if (is_inner) {
+        inner_visit<FAST, COUNT>(P, o, d, T, stk, cn);
+        done = trav_advance(T, stk);
+    }
+    if (!inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min) {
+        if (is_leaf) {
+            leaf_visit<COUNT>(P, o, d, T, cn);
+            done = trav_advance(T, stk);
+        }
+    }
+    return done;
+}
+
+/* the sphere loop of calculate_ray_collision, shader.wgsl:144-154 */
+__device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V3 d, float &best, int32_t &id) {
+    best = PT_FAR;
+    id = PT_NONE;
     for (uint32_t k = 0; k < P.sphere_count; k++) {
         float dst;
         if (ray_sphere(o, d, P.spheres + 12 * k, dst) && dst < best) { best = dst; id = -(int32_t)(1 + k); }
     }
-    float bt; int32_t bid;
-    bvh_closest<COUNT>(P, o, d, stk, bt, bid, cn);
-    if (bid != PT_NONE && bt < best) { best = bt; id = bid; }
-    if (COUNT) cn.casts++;
+}
+
+/* calculate_ray_collision, shader.wgsl:139-163, one whole cast for this lane: spheres in
+ * index order, then the BVH (which does not see the sphere distance), strict `<`
+ * everywhere.  `active` lanes take part; the division form is chosen per wave. */
+template <bool COUNT>
+__device__ __forceinline__ void closest_hit(const PTKernelParams &P, bool active, V3 o, V3 d, uint32_t *stk,
+                                            float &t_out, int32_t &id_out, Counters &cn) {
+    float best = PT_FAR;
+    int32_t id = PT_NONE;
+    const bool fast = P.fast_div && __all(!active || ray_div_safe(o, d));
+    if (active) {
+        spheres_closest(P, o, d, best, id);
+    }
+    Trav T;
+    trav_begin(P, d, T);
+    bool traversing = active;
+    while (__ballot(traversing)) {
+        bool done = fast ? trav_wave_step<true, COUNT>(P, traversing, o, d, T, stk, cn)
+                         : trav_wave_step<false, COUNT>(P, traversing, o, d, T, stk, cn);
+        if (done) traversing = false;
+    }
+    if (active) {
+        if (T.best_id != PT_NONE && T.best_t < best) { best = T.best_t; id = T.best_id; }
+        if (COUNT) cn.casts++;
+    }
     t_out = best;
     id_out = id;
 }
@@ -347,10 +458,8 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     uint32_t pixel_index = 0;
     float t = PT_FAR;
     int32_t id = PT_NONE;
-    if (valid) {
-        primary_ray(P, px, py, rd, pixel_index);
-        closest_hit<COUNT>(P, ro, rd, stk, t, id, cn);
-    }
+    if (valid) primary_ray(P, px, py, rd, pixel_index);
+    closest_hit<COUNT>(P, valid, ro, rd, stk, t, id, cn);
     const uint32_t pixel = py * P.width + px;
     if (AOV) {
         if (valid) { P.out_ids[pixel] = id; P.out_dist[pixel] = t; }
@@ -385,8 +494,23 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 }
 
 /* ======================= bounces ======================= */
+/*
+ * Lane phases of the persistent path kernel.  A lane owns one path at a time; the
+ * BVH traversal of its current ray is resumable (Trav), so a wave does not have
+ * to wait for its slowest lane: as soon as PT_REFILL_MIN lanes have finished
+ * their traversal the wave leaves the traversal loop, shades those lanes (which
+ * either produces their next ray or ends the path and pulls a new one from the
+ * global queue) and re-enters the loop with the other lanes' traversals intact.
+ */
+#define PT_PHASE_IDLE 0      /* no path: wants one from the queue */
+#define PT_PHASE_RAY 1       /* has a ray that has not started its cast */
+#define PT_PHASE_TRAV 2      /* BVH traversal in progress */
+#define PT_PHASE_HIT 3       /* cast complete, waiting to be shaded */
+#define PT_PHASE_DEAD 4      /* queue drained and path finished */
+#define PT_REFILL_MIN 16
+
 template <int STACK, bool EXACT, bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
+__global__ __launch_bounds__(PT_BLOCK, 5) void path_kernel(PTKernelParams P) {
     __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *stk = &stack[wave][0][lane];
@@ -394,62 +518,116 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
     const uint32_t total = P.ctrl->hit_count * rpp;
     Counters cn = {0, 0, 0, 0};
 
-    bool active = false, drained = false;
+    int phase = PT_PHASE_IDLE;
+    bool drained = false;
     uint32_t item = 0, seed = 0, i = 0;
-    V3 ro = mk(0, 0, 0), rd = mk(0, 0, 0), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
+    V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
+    Trav T;
+    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = PT_FAR; T.best_id = PT_NONE; T.inv = mk(0, 0, 0);
+    float sph_t = PT_FAR;
+    int32_t sph_id = PT_NONE;
+    bool safe = false;
+    WaveStats ws = {0, 0, 0, 0};
+    unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0;
+    if (COUNT) t_start = __builtin_amdgcn_s_memtime();
 
     for (;;) {
-        unsigned long long need = __ballot(!active);
-        if (need && !drained) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&P.ctrl->next_item, (uint32_t)__popcll(need));
-            base = __shfl(base, 0, 64);
-            if (base >= total) drained = true;
-            if (!active) {
-                item = base + prefix_count(need);
-                if (item < total) {
-                    /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
-                    PTHitRecord h = P.hits[item / rpp];
-                    uint32_t s = item % rpp;
-                    uint32_t px = h.pixel % P.width, py = h.pixel / P.width;
-                    uint32_t pixel_index;
-                    primary_ray(P, px, py, rd, pixel_index);
-                    ro = ld3(P.cam_pos);
-                    seed = pixel_index + s * 248135u;                      /* shader.wgsl:100 */
-                    light = mk(0.0f, 0.0f, 0.0f);
-                    ray_color = mk(1.0f, 1.0f, 1.0f);
-                    Surface sf = surface_of(P, ro, rd, h.distance, h.prim_id);
-                    bounce<EXACT>(P, sf, seed, 0u, ro, rd, light, ray_color);
-                    i = 1;
-                    active = true;
-                }
-            }
-        }
-        if (!__ballot(active)) break;
-        if (active) {
+        if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(phase == PT_PHASE_HIT)); }
+        /* (A) shade the lanes whose cast is complete: one iteration of trace, shader.wgsl:118-133 */
+        if (phase == PT_PHASE_HIT) {
+            float t = sph_t;
+            int32_t id = sph_id;
+            if (T.best_id != PT_NONE && T.best_t < t) { t = T.best_t; id = T.best_id; }
             bool finished;
-            if (i > P.max_bounce_count) {
-                finished = true;                                           /* loop bound reached, no sky term */
+            if (id != PT_NONE) {
+                Surface sf = surface_of(P, ro, rd, t, id);
+                bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
+                i++;
+                finished = i > P.max_bounce_count;            /* loop bound reached: no sky term */
             } else {
-                float t; int32_t id;
-                closest_hit<COUNT>(P, ro, rd, stk, t, id, cn);
-                if (id != PT_NONE) {
-                    Surface sf = surface_of(P, ro, rd, t, id);
-                    bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
-                    i++;
-                    finished = i > P.max_bounce_count;
-                } else {
-                    if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
-                    finished = true;
-                }
+                if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
+                finished = true;
             }
             if (finished) {
                 P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
-                active = false;
+                phase = PT_PHASE_IDLE;
+            } else {
+                phase = PT_PHASE_RAY;
             }
         }
+        /* (B) idle lanes pull new paths: one atomic per wave */
+        unsigned long long need = __ballot(phase == PT_PHASE_IDLE);
+        if (need) {
+            if (!drained) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&P.ctrl->next_item, (uint32_t)__popcll(need));
+                base = __shfl(base, 0, 64);
+                if (base + (uint32_t)__popcll(need) >= total) drained = true;   /* this grab reached the end */
+                if (phase == PT_PHASE_IDLE) {
+                    item = base + prefix_count(need);
+                    if (item < total) {
+                        /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
+                        PTHitRecord h = P.hits[item / rpp];
+                        uint32_t s = item % rpp;
+                        uint32_t px = h.pixel % P.width, py = h.pixel / P.width;
+                        uint32_t pixel_index;
+                        primary_ray(P, px, py, rd, pixel_index);
+                        ro = ld3(P.cam_pos);
+                        seed = pixel_index + s * 248135u;                      /* shader.wgsl:100 */
+                        light = mk(0.0f, 0.0f, 0.0f);
+                        ray_color = mk(1.0f, 1.0f, 1.0f);
+                        Surface sf = surface_of(P, ro, rd, h.distance, h.prim_id);
+                        bounce<EXACT>(P, sf, seed, 0u, ro, rd, light, ray_color);
+                        i = 1;
+                        if (i > P.max_bounce_count) {                           /* max_bounce_count == 0 */
+                            P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
+                        } else {
+                            phase = PT_PHASE_RAY;
+                        }
+                    }
+                }
+            }
+            if (drained && phase == PT_PHASE_IDLE) phase = PT_PHASE_DEAD;
+        }
+        /* (C) new rays: spheres first (shader.wgsl:144-154), then set up the traversal */
+        if (phase == PT_PHASE_RAY) {
+            spheres_closest(P, ro, rd, sph_t, sph_id);
+            trav_begin(P, rd, T);
+            safe = ray_div_safe(ro, rd);
+            if (COUNT) cn.casts++;
+            phase = PT_PHASE_TRAV;
+        }
+        if (!__ballot(phase != PT_PHASE_DEAD)) break;
+        /* (D) traverse until enough lanes wait for shading (or, at the tail, all are done) */
+        const bool fast = P.fast_div && __all(phase != PT_PHASE_TRAV || safe);
+        unsigned long long t0 = 0;
+        if (COUNT) t0 = __builtin_amdgcn_s_memtime();
+        for (;;) {
+            unsigned long long trav = __ballot(phase == PT_PHASE_TRAV);
+            if (!trav) break;
+            unsigned long long waiting = __ballot(phase == PT_PHASE_HIT);
+            if ((uint32_t)__popcll(waiting) >= P.refill_min) break;
+            const bool traversing = phase == PT_PHASE_TRAV;
+            bool done = fast ? trav_wave_step<true, COUNT>(P, traversing, ro, rd, T, stk, cn, &ws)
+                             : trav_wave_step<false, COUNT>(P, traversing, ro, rd, T, stk, cn, &ws);
+            if (done) phase = PT_PHASE_HIT;
+        }
+        if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
     }
-    if (COUNT) flush_counters(P, cn, 1ull, true);
+    if (COUNT) {
+        flush_counters(P, cn, 1ull, true);
+        /* diagnostics: where a wave's time and lanes go (pt_get_debug_stats) */
+        if (lane == 0) {
+            atomicAdd(&P.counters[8], __builtin_amdgcn_s_memtime() - t_start);
+            atomicAdd(&P.counters[9], t_trav);
+            atomicAdd(&P.counters[10], ws.steps);
+            atomicAdd(&P.counters[11], ws.inner_lanes);
+            atomicAdd(&P.counters[12], ws.leaf_lanes);
+            atomicAdd(&P.counters[13], ws.leaf_runs);
+            atomicAdd(&P.counters[14], outer_iters);
+            atomicAdd(&P.counters[15], shade_lanes);
+        }
+    }
 }
 
 /* ======================= per-pixel resolve ======================= */

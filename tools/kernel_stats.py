@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Prints the path kernel's lane/time diagnostics for one frame of a config (needs a GPU)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as entry
+pkg = entry.load_package()
+from path_tracing_amd import scenes
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+cfg = scenes.config(n)
+tris, bvh = scenes.mesh(cfg["mesh"])
+p = pkg.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=cfg["rays_per_pixel"],
+                       max_bounce_count=cfg["max_bounce_count"], flags=pkg.PT_FLAG_COUNT_WORK)
+with pkg.Renderer(p) as r:
+    r.upload_scene(scenes.spheres_for(cfg["spheres"]), tris, bvh)
+    r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+    r.render_frames(0, 1)
+    c, d, t = r.counters(), r.debug_stats(), r.timing()
+print(c); print(d); print(t)
+print("trav share of wave time %.3f" % (d["trav_clocks"] / d["wave_clocks"]))
+print("inner lanes/step %.1f  leaf runs/step %.3f  leaf lanes/run %.1f" % (
+    d["inner_lanes"] / d["trav_steps"], d["leaf_runs"] / d["trav_steps"], d["leaf_lanes"] / max(1, d["leaf_runs"])))
+print("outer iters %d  shade lanes/iter %.1f  steps/outer %.1f" % (d["outer_iters"], d["shade_lanes"] / d["outer_iters"], d["trav_steps"] / d["outer_iters"]))
+print("inner visits/cast %.1f (boxes/2=%.1f)" % (d["inner_lanes"] / c["path_kernel_ray_casts"], c["path_kernel_box_tests"] / 2 / c["path_kernel_ray_casts"]))

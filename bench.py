@@ -134,6 +134,7 @@ def main():
             },
             "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])
                                     for k in ("primary_ms", "path_ms", "resolve_ms")},
+            "kernel_launches_per_step": timing["batches"] / max(1, args.steps),
         }
 
     # ---- roofline of the dominant kernel (rank 0) -------------------------
@@ -152,16 +153,17 @@ def main():
             S = len(spheres)
             path_bytes = 36 * cnt["path_kernel_box_tests"] + 36 * cnt["path_kernel_tri_tests"] \
                 + 48 * S * cnt["path_kernel_ray_casts"]
-            per_launch = path_bytes / frames_local
-            avg_ms = timing["path_ms"] / timing["frames"]
+            launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
+            per_launch = path_bytes / launches_per_step
+            avg_ms = timing["path_ms"] / timing["batches"]
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             all_bytes = 36 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 48 * S * cnt["ray_casts"] \
                 + 32 * W * H * frames_local
             roof.update({
                 "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms,
-                "launches_timed": int(timing["frames"]),
-                "ray_casts_per_launch": cnt["path_kernel_ray_casts"] / frames_local,
+                "launches_timed": int(timing["batches"]), "frames_per_launch": frames_local / launches_per_step,
+                "ray_casts_per_launch": cnt["path_kernel_ray_casts"] / launches_per_step,
                 "box_tests_per_cast": cnt["path_kernel_box_tests"] / max(1, cnt["path_kernel_ray_casts"]),
                 "tri_tests_per_cast": cnt["path_kernel_tri_tests"] / max(1, cnt["path_kernel_ray_casts"]),
                 "frac_of_l2_peak": achieved / L2_PEAK_GBS, "frac_of_mall_peak": achieved / MALL_PEAK_GBS,

@@ -89,6 +89,7 @@ typedef struct pt_counters {
  * pt_reset_timing (events are recorded on the context's stream). */
 typedef struct pt_timing {
     uint64_t frames;           /* frames rendered */
+    uint64_t batches;          /* launches of each kernel (frames are rendered in batches) */
     double primary_ms;         /* primary-ray kernel, summed */
     double path_ms;            /* bounce/path kernel (the dominant one), summed */
     double resolve_ms;         /* per-pixel resolve + accumulation kernel, summed */

@@ -49,7 +49,7 @@ class PtCounters(C.Structure):
 
 
 class PtTiming(C.Structure):
-    _fields_ = [("frames", C.c_uint64), ("primary_ms", C.c_double),
+    _fields_ = [("frames", C.c_uint64), ("batches", C.c_uint64), ("primary_ms", C.c_double),
                 ("path_ms", C.c_double), ("resolve_ms", C.c_double)]
 
     def as_dict(self):

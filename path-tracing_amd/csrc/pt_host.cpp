@@ -42,6 +42,9 @@ struct pt_ctx {
     PTHitRecord *d_hits = nullptr;
     PTControl *d_ctrl = nullptr;
     float4 *d_samples = nullptr;
+    uint32_t *d_pixel_hit = nullptr;
+    float4 *d_pixel_const = nullptr;
+    uint32_t max_batch = 1;            /* frames whose samples fit the sample buffer */
     unsigned long long *d_counters = nullptr;
     int32_t *d_ids = nullptr;
     float *d_dist = nullptr;
@@ -226,12 +229,17 @@ int validate_params(const pt_params *p, std::string &why) {
     return PT_OK;
 }
 
-void fill_kernel_params(const pt_ctx *c, uint32_t frame_count, uint32_t accum_mode, PTKernelParams &k) {
+void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_stride, uint32_t batch_frames,
+                        uint32_t accum_mode, PTKernelParams &k) {
     memset(&k, 0, sizeof(k));
     const pt_params &p = c->params;
     k.width = p.width; k.height = p.height;
     k.rays_per_pixel = p.rays_per_pixel; k.max_bounce_count = p.max_bounce_count;
-    k.frame_count = frame_count; k.accum_mode = accum_mode;
+    k.frame_first = frame_first; k.frame_stride = frame_stride; k.batch_frames = batch_frames;
+    k.div_width = pt_fastdiv_make(p.width);
+    k.div_rpp = pt_fastdiv_make(p.rays_per_pixel);
+    k.div_batch = pt_fastdiv_make(batch_frames);
+    k.accum_mode = accum_mode;
     k.width_f = (float)p.width; k.height_f = (float)p.height;
     /* vs_main, shader.wgsl:36-37,68-69.  fov is a const-expression of abstract
      * floats (f64, rounded once); tan is taken in double and rounded once. */
@@ -269,6 +277,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_count, uint32_t accum_mo
     k.leaf_min = c->leaf_min;
     k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
+    k.pixel_hit = c->d_pixel_hit; k.pixel_const = c->d_pixel_const;
     k.out_ids = c->d_ids; k.out_dist = c->d_dist; k.counters = c->d_counters;
 }
 
@@ -306,14 +315,21 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
     HIP_TRY(c, hipSetDevice(c->device));
     const bool exact = (c->params.flags & PT_FLAG_EXACT_MATH) != 0;
     const bool count = (c->params.flags & PT_FLAG_COUNT_WORK) != 0;
-    for (uint32_t f = 0; f < n_frames; f++) {
+    /* Frames are rendered in batches: camera and scene are constant within the call, so the
+     * primary rays (identical for every sample of every frame, shader.wgsl:80-101) are cast once
+     * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
+     * and the resolve kernel folds the frames into the accumulation buffer in frame order. */
+    for (uint32_t done = 0; done < n_frames;) {
+        uint32_t batch = n_frames - done < c->max_batch ? n_frames - done : c->max_batch;
         PTKernelParams k;
-        fill_kernel_params(c, first + f * stride, mode, k);
+        fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
         HIP_TRY(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(PTControl), c->stream));
         { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, c->stack_entries, exact, count, false, c->stream)); t.done(); }
         { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, c->stack_entries, exact, count, c->num_cus, c->stream)); t.done(); }
         { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
-        c->timing.frames++;
+        c->timing.frames += batch;
+        c->timing.batches++;
+        done += batch;
         if (c->pending.size() > 3000) {       /* bound the number of live events on long renders */
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             int rc = drain_events(c);
@@ -394,7 +410,20 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->d_accum = c->d_accum_own;
     if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
     if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
-    if ((e = hipMalloc(&c->d_samples, npix * params->rays_per_pixel * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(samples)");
+    /* sample buffer: as many frames per batch as fit the budget (default 12 GiB, PT_SAMPLE_BUDGET_MB) */
+    {
+        size_t budget = (size_t)12 << 30;
+        if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
+        size_t per_frame = npix * params->rays_per_pixel * sizeof(float4);
+        size_t nb = budget / per_frame;
+        if (nb < 1) nb = 1;
+        if (nb > 64) nb = 64;
+        if (const char *ev = getenv("PT_MAX_BATCH")) { long v = atol(ev); if (v >= 1 && (size_t)v < nb) nb = (size_t)v; }
+        c->max_batch = (uint32_t)nb;
+        if ((e = hipMalloc(&c->d_samples, per_frame * nb)) != hipSuccess) return bail(e, "hipMalloc(samples)");
+    }
+    if ((e = hipMalloc(&c->d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pixel_hit)");
+    if ((e = hipMalloc(&c->d_pixel_const, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(pixel_const)");
     if ((e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -531,7 +560,7 @@ int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
     if (!c->d_ids) HIP_TRY(c, hipMalloc(&c->d_ids, npix * sizeof(int32_t)));
     if (!c->d_dist) HIP_TRY(c, hipMalloc(&c->d_dist, npix * sizeof(float)));
     PTKernelParams k;
-    fill_kernel_params(c, 0, 0, k);
+    fill_kernel_params(c, 0, 1, 1, 0, k);
     HIP_TRY(c, pt_launch_primary(k, c->stack_entries, true, false, true, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(prim_id, c->d_ids, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -617,6 +646,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
+    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

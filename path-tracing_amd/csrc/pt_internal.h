@@ -40,7 +40,22 @@ struct PTHitRecord {
     uint32_t pad;
 };
 
-/* control words in device memory, zeroed before each frame */
+/* Unsigned division by a run-time constant (Granlund-Montgomery): n / d for any 32-bit n,
+ * d >= 1, as one mulhi, one add and two shifts.  Used to split a path-queue index into
+ * (hit pixel, frame, sample) without integer division sequences. */
+struct PTFastDiv { uint32_t d, mul, sh1, sh2; };
+static inline PTFastDiv pt_fastdiv_make(uint32_t d) {
+    PTFastDiv f;
+    uint32_t l = 0;
+    while ((1ull << l) < d) l++;
+    f.d = d;
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 0 ? l - 1 : 0;
+    return f;
+}
+
+/* control words in device memory, zeroed before each batch of frames */
 struct PTControl {
     uint32_t hit_count;     /* number of PTHitRecord written by the primary kernel */
     uint32_t next_item;     /* path-kernel work queue head */
@@ -49,7 +64,11 @@ struct PTControl {
 
 struct PTKernelParams {
     uint32_t width, height, rays_per_pixel, max_bounce_count;
-    uint32_t frame_count;
+    uint32_t frame_first;          /* frame_count of the first frame of this batch */
+    uint32_t frame_stride;         /* frame_count step between the frames of the batch */
+    uint32_t batch_frames;         /* frames rendered by this batch of launches */
+    PTFastDiv div_width;           /* pixel -> row */
+    PTFastDiv div_rpp, div_batch;  /* queue index = (hit * batch_frames + frame) * rays_per_pixel + sample */
     uint32_t accum_mode;           /* 0: running mean (shader.wgsl:104-106), 1: add the frame mean */
     float width_f, height_f, screen_w, screen_h;
     float cam_pos[3];
@@ -69,7 +88,9 @@ struct PTKernelParams {
     float4 *accum;
     PTHitRecord *hits;
     PTControl *ctrl;
-    float4 *samples;
+    float4 *samples;               /* radiance of every path, indexed like the queue */
+    uint32_t *pixel_hit;           /* per pixel: index into hits, or 0xffffffff when the primary ray missed */
+    float4 *pixel_const;           /* per miss pixel: its frame mean (the same in every frame) */
     int32_t *out_ids;
     float *out_dist;
     unsigned long long *counters;  /* 8 words, see flush_counters */

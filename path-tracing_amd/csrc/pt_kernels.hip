@@ -381,12 +381,13 @@ __device__ __forceinline__ V3 environment_light(const PTKernelParams &P, V3 dir)
     return mk(r.x + ss, r.y + ss, r.z + ss);
 }
 
-/* one "hit" iteration of trace, shader.wgsl:119-127 */
+/* one "hit" iteration of trace, shader.wgsl:119-127.  `seed` already contains the
+ * frame term: seed = pixel_index + sample * 248135 + frame_count * 393939123 (u32 wrap). */
 template <bool EXACT>
 __device__ __forceinline__ void bounce(const PTKernelParams &P, const Surface &s, uint32_t seed, uint32_t i,
                                        V3 &ro, V3 &rd, V3 &light, V3 &ray_color) {
     ro = s.position;
-    uint32_t rs = seed + i * 12345u + P.frame_count * 393939123u;
+    uint32_t rs = seed + i * 12345u;
     V3 diffuse_dir = normalize3(s.normal + random_direction<EXACT>(rs));
     float dn2 = 2.0f * dot3(s.normal, rd);
     V3 specular_dir = rd - s.normal * dn2;
@@ -396,20 +397,21 @@ __device__ __forceinline__ void bounce(const PTKernelParams &P, const Surface &s
     ray_color = ray_color * s.color;
 }
 
-/* the tail of fs_main, shader.wgsl:102-106, or the summing form used by frame-sharded renders */
-__device__ __forceinline__ void accumulate(const PTKernelParams &P, uint32_t pixel, V3 sum) {
+/* the tail of fs_main, shader.wgsl:102-106, for one frame: `acc` is the pixel's accumulation
+ * value, `sum` the sum of the frame's samples in sample order */
+__device__ __forceinline__ V3 fold_frame(const PTKernelParams &P, V3 acc, V3 sum, uint32_t frame_count) {
     float n = (float)P.rays_per_pixel;
     V3 pixel_color = mk(sum.x / n, sum.y / n, sum.z / n);
-    float4 old = P.accum[pixel];
-    float4 out;
     if (P.accum_mode == 0) {
-        float weight = 1.0f / (float)(P.frame_count + 1u);
-        V3 wa = mk(old.x, old.y, old.z) * (1.0f - weight) + pixel_color * weight;
-        out = make_float4(wa.x, wa.y, wa.z, 0.0f);
-    } else {
-        out = make_float4(old.x + pixel_color.x, old.y + pixel_color.y, old.z + pixel_color.z, 0.0f);
+        float weight = 1.0f / (float)(frame_count + 1u);
+        return acc * (1.0f - weight) + pixel_color * weight;
     }
-    P.accum[pixel] = out;
+    return acc + pixel_color;             /* frame-sharded renders keep a sum */
+}
+
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, PTFastDiv f) {
+    uint32_t t = __umulhi(f.mul, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
 __device__ __forceinline__ uint32_t lane_id() {
@@ -468,28 +470,35 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const bool hit = valid && id != PT_NONE;
     /* compact the hit pixels of this wave into the global list: one atomic per wave */
     unsigned long long mask = __ballot(hit);
+    uint32_t hit_index = 0xffffffffu;
     if (mask) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&P.ctrl->hit_count, (uint32_t)__popcll(mask));
         base = __shfl(base, 0, 64);
         if (hit) {
+            hit_index = base + prefix_count(mask);
             PTHitRecord r;
             r.pixel = pixel; r.prim_id = id; r.distance = t; r.pad = 0;
-            P.hits[base + prefix_count(mask)] = r;
+            P.hits[hit_index] = r;
         }
     }
-    if (valid && !hit) {
-        /* every sample of the pixel is the same environment lookup (trace breaks at the first cast) */
-        V3 e = mk(0.0f, 0.0f, 0.0f);
-        if (P.use_env) e = environment_light<EXACT>(P, rd) * mk(1.0f, 1.0f, 1.0f);
-        V3 incoming = mk(0.0f, 0.0f, 0.0f) + e;
-        V3 sum = mk(0.0f, 0.0f, 0.0f);
-        for (uint32_t s = 0; s < P.rays_per_pixel; s++) sum = sum + incoming;
-        accumulate(P, pixel, sum);
+    if (valid) {
+        P.pixel_hit[pixel] = hit_index;
+        if (!hit) {
+            /* every sample of every frame is the same environment lookup (trace breaks at its
+             * first cast, shader.wgsl:128-132): store the sum over the samples of one frame */
+            V3 e = mk(0.0f, 0.0f, 0.0f);
+            if (P.use_env) e = environment_light<EXACT>(P, rd) * mk(1.0f, 1.0f, 1.0f);
+            V3 incoming = mk(0.0f, 0.0f, 0.0f) + e;
+            V3 sum = mk(0.0f, 0.0f, 0.0f);
+            for (uint32_t s = 0; s < P.rays_per_pixel; s++) sum = sum + incoming;
+            P.pixel_const[pixel] = make_float4(sum.x, sum.y, sum.z, 0.0f);
+        }
     }
     if (COUNT) {
         if (valid) cn.paths = 1;
-        flush_counters(P, cn, P.rays_per_pixel, false);   /* the reference repeats the primary cast for every sample */
+        /* the reference repeats the primary cast for every sample of every frame */
+        flush_counters(P, cn, (unsigned long long)P.rays_per_pixel * P.batch_frames, false);
     }
 }
 
@@ -510,12 +519,12 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_REFILL_MIN 16
 
 template <int STACK, bool EXACT, bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK, 5) void path_kernel(PTKernelParams P) {
+__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
     __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *stk = &stack[wave][0][lane];
     const uint32_t rpp = P.rays_per_pixel;
-    const uint32_t total = P.ctrl->hit_count * rpp;
+    const uint32_t total = P.ctrl->hit_count * P.batch_frames * rpp;
     Counters cn = {0, 0, 0, 0};
 
     int phase = PT_PHASE_IDLE;
@@ -567,13 +576,19 @@ __global__ __launch_bounds__(PT_BLOCK, 5) void path_kernel(PTKernelParams P) {
                     item = base + prefix_count(need);
                     if (item < total) {
                         /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
-                        PTHitRecord h = P.hits[item / rpp];
-                        uint32_t s = item % rpp;
-                        uint32_t px = h.pixel % P.width, py = h.pixel / P.width;
+                        /* queue index -> (hit pixel, frame of the batch, sample) */
+                        uint32_t hf = fast_div(item, P.div_rpp);
+                        uint32_t s = item - hf * rpp;
+                        uint32_t hi = fast_div(hf, P.div_batch);
+                        uint32_t frame_count = P.frame_first + (hf - hi * P.batch_frames) * P.frame_stride;
+                        PTHitRecord h = P.hits[hi];
+                        uint32_t py = fast_div(h.pixel, P.div_width);
+                        uint32_t px = h.pixel - py * P.width;
                         uint32_t pixel_index;
                         primary_ray(P, px, py, rd, pixel_index);
                         ro = ld3(P.cam_pos);
-                        seed = pixel_index + s * 248135u;                      /* shader.wgsl:100 */
+                        /* shader.wgsl:100 and :121, folded: the frame term is the same for every bounce */
+                        seed = pixel_index + s * 248135u + frame_count * 393939123u;
                         light = mk(0.0f, 0.0f, 0.0f);
                         ray_color = mk(1.0f, 1.0f, 1.0f);
                         Surface sf = surface_of(P, ro, rd, h.distance, h.prim_id);
@@ -631,17 +646,32 @@ __global__ __launch_bounds__(PT_BLOCK, 5) void path_kernel(PTKernelParams P) {
 }
 
 /* ======================= per-pixel resolve ======================= */
+/* One thread per pixel: folds the frames of the batch into the accumulation buffer in frame
+ * order (shader.wgsl:99-106): per frame the samples are added in sample order, divided by
+ * rays_per_pixel and blended with weight 1/(frame_count+1).  One read-modify-write of the
+ * pixel per batch. */
 __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= P.ctrl->hit_count) return;
-    const uint32_t pixel = P.hits[h].pixel;
-    const float4 *s = P.samples + (size_t)h * P.rays_per_pixel;
-    V3 sum = mk(0.0f, 0.0f, 0.0f);
-    for (uint32_t k = 0; k < P.rays_per_pixel; k++) {          /* shader.wgsl:99-101, in sample order */
-        float4 v = s[k];
-        sum = sum + mk(v.x, v.y, v.z);
+    const uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pixel >= P.width * P.height) return;
+    const uint32_t h = P.pixel_hit[pixel];
+    float4 a4 = P.accum[pixel];
+    V3 acc = mk(a4.x, a4.y, a4.z);
+    if (h == 0xffffffffu) {
+        float4 c = P.pixel_const[pixel];
+        for (uint32_t b = 0; b < P.batch_frames; b++)
+            acc = fold_frame(P, acc, mk(c.x, c.y, c.z), P.frame_first + b * P.frame_stride);
+    } else {
+        const float4 *s = P.samples + (size_t)h * P.batch_frames * P.rays_per_pixel;
+        for (uint32_t b = 0; b < P.batch_frames; b++) {
+            V3 sum = mk(0.0f, 0.0f, 0.0f);
+            for (uint32_t k = 0; k < P.rays_per_pixel; k++) {          /* shader.wgsl:99-101, in sample order */
+                float4 v = s[b * P.rays_per_pixel + k];
+                sum = sum + mk(v.x, v.y, v.z);
+            }
+            acc = fold_frame(P, acc, sum, P.frame_first + b * P.frame_stride);
+        }
     }
-    accumulate(P, pixel, sum);
+    P.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, float s) {
@@ -716,7 +746,7 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, int stack_entries, bool exa
 }
 
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t st) {
-    uint32_t n = kp.width * kp.height;   /* upper bound of the hit list; surplus threads exit */
+    uint32_t n = kp.width * kp.height;
     hipLaunchKernelGGL(resolve_kernel, dim3((n + 255) / 256), dim3(256), 0, st, kp);
     return hipGetLastError();
 }

@@ -29,7 +29,7 @@ def test_struct_layouts_match_header(pkg):
     # pt_params: 5 x 4 bytes + 6 + 2 + 9 + 3 + 2 floats + 2 u32 -> 4-byte fields only
     assert C.sizeof(pkg.PtParams) == 4 * (4 + 1 + 3 + 3 + 1 + 1 + 3 + 3 + 3 + 3 + 1 + 1 + 1 + 1)
     assert C.sizeof(pkg.PtCounters) == 7 * 8
-    assert C.sizeof(pkg.PtTiming) == 8 + 3 * 8
+    assert C.sizeof(pkg.PtTiming) == 2 * 8 + 3 * 8
 
 
 def test_default_params_are_the_reference_constants(pkg):

@@ -275,6 +275,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
     k.leaf_min = c->leaf_min;
+    k.xcd_queues = getenv("PT_NO_XCD_QUEUES") ? 0u : 1u;
     k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
     k.pixel_hit = c->d_pixel_hit; k.pixel_const = c->d_pixel_const;

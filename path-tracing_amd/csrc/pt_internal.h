@@ -58,8 +58,9 @@ static inline PTFastDiv pt_fastdiv_make(uint32_t d) {
 /* control words in device memory, zeroed before each batch of frames */
 struct PTControl {
     uint32_t hit_count;     /* number of PTHitRecord written by the primary kernel */
-    uint32_t next_item;     /* path-kernel work queue head */
-    uint32_t pad[14];
+    uint32_t pad0;
+    uint32_t queue_head[8]; /* path-kernel work queue heads, one per XCD part */
+    uint32_t pad[6];
 };
 
 struct PTKernelParams {
@@ -78,6 +79,7 @@ struct PTKernelParams {
     uint32_t use_env;
     uint32_t sphere_count;
     uint32_t root_ref;
+    uint32_t xcd_queues;           /* 1: a block starts on the queue part of the XCD it runs on; 0: blockIdx % 8 */
     uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */
     uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
     uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */

@@ -23,6 +23,7 @@
  * are reproducible bit for bit on a CPU.
  */
 #include "pt_internal.h"
+#include <cstdlib>
 #include "pt_portable_math.h"
 #include "pt_exact_div.h"
 
@@ -524,11 +525,16 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     uint32_t *stk = &stack[wave][0][lane];
     const uint32_t rpp = P.rays_per_pixel;
-    const uint32_t total = P.ctrl->hit_count * P.batch_frames * rpp;
+    const uint32_t per_hit = P.batch_frames * rpp;
+    const uint32_t total = P.ctrl->hit_count * per_hit;
+    const uint32_t part = ((P.ctrl->hit_count + 7u) / 8u) * per_hit;     /* whole pixels per part */
+    /* XCC_ID: bits 3:0 of hardware register 20 */
+    uint32_t queue = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
+    uint32_t queues_done = 0;
     Counters cn = {0, 0, 0, 0};
 
     int phase = PT_PHASE_IDLE;
-    bool drained = false;
+    bool drained = total == 0;
     uint32_t item = 0, seed = 0, i = 0;
     V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
     Trav T;
@@ -564,17 +570,23 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
                 phase = PT_PHASE_RAY;
             }
         }
-        /* (B) idle lanes pull new paths: one atomic per wave */
+        /* (B) idle lanes pull new paths: one atomic per wave.  The queue is cut into 8 equal,
+         * contiguous parts, one per XCD (consecutive paths belong to neighbouring pixels, so a
+         * part is a compact piece of the image and the BVH nodes its rays visit stay in that
+         * XCD's 4 MiB L2).  A wave drains its own XCD's part first, then helps the others. */
         unsigned long long need = __ballot(phase == PT_PHASE_IDLE);
         if (need) {
-            if (!drained) {
+            while (!drained) {
+                const uint32_t q_start = queue * part < total ? queue * part : total;
+                const uint32_t q_len = (total - q_start < part) ? total - q_start : part;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&P.ctrl->next_item, (uint32_t)__popcll(need));
+                if (lane == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
                 base = __shfl(base, 0, 64);
-                if (base + (uint32_t)__popcll(need) >= total) drained = true;   /* this grab reached the end */
-                if (phase == PT_PHASE_IDLE) {
-                    item = base + prefix_count(need);
-                    if (item < total) {
+                const bool exhausted = base + (uint32_t)__popcll(need) >= q_len;
+                if (base < q_len && phase == PT_PHASE_IDLE) {
+                    const uint32_t local = base + prefix_count(need);
+                    if (local < q_len) {
+                        item = q_start + local;
                         /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
                         /* queue index -> (hit pixel, frame of the batch, sample) */
                         uint32_t hf = fast_div(item, P.div_rpp);
@@ -601,6 +613,11 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
                         }
                     }
                 }
+                if (exhausted) {
+                    queue = (queue + 1u) & 7u;
+                    if (++queues_done == 8u) drained = true;
+                }
+                if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
             }
             if (drained && phase == PT_PHASE_IDLE) phase = PT_PHASE_DEAD;
         }
@@ -707,6 +724,7 @@ static hipError_t launch_paths_s(const PTKernelParams &kp, bool exact, bool coun
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
+    if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu), block(PT_BLOCK);
     if (count) {
         if (exact) hipLaunchKernelGGL((path_kernel<STACK, true, true>), grid, block, 0, st, kp);

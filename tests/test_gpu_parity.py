@@ -191,3 +191,45 @@ def test_errors_are_reported_not_fatal(pkg, scenes):
         pkg.Renderer(pkg.default_params(width=0, height=10), device=0)
     with pytest.raises(pkg.PtError):
         pkg.Renderer(params, device=99)
+
+
+def test_batches_smaller_than_the_render(pkg, scenes, oracle_shared, monkeypatch):
+    """Frames are rendered in batches (primary rays once per batch, one path queue per batch).
+    Force 2-frame batches for a 5-frame render: still bit-exact, also in sum mode with a stride."""
+    monkeypatch.setenv("PT_MAX_BATCH", "2")
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=3)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    with r:
+        r.render_frames(0, 5)
+        img = r.read_accum(4)
+        assert r.timing()["batches"] == 3 and r.timing()["frames"] == 5
+        r.reset_accum()
+        r.render_frames_sum(1, 3, 2)                      # frames 1, 3, 5
+        s = r.read_accum(4)
+    oimg = oracle_shared.render_frames(op, sc, cam, rot, 0, 5)
+    assert np.array_equal(bits(img[..., :3]), bits(oimg[..., :3]))
+    osum = oracle_shared.render_frames_sum(op, sc, cam, rot, 1, 3, 2)
+    assert np.array_equal(bits(s[..., :3]), bits(osum[..., :3]))
+
+
+def test_slow_division_path_agrees(pkg, scenes, oracle_shared, monkeypatch):
+    """ray_box has two division back ends (plain IEEE / reciprocal + FMA corrections): both must give
+    the oracle's bits.  PT_NO_FAST_DIV forces the plain one; an axis-aligned camera exercises the
+    per-ray fallback (direction components of exactly 0 are outside the reciprocal form's domain)."""
+    monkeypatch.setenv("PT_NO_FAST_DIV", "1")
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH,
+                            width=96, height=54, rays_per_pixel=2)
+    with r:
+        r.render(2)
+        img = r.read_accum(4)
+    oimg = oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 2)
+    assert np.array_equal(bits(img[..., :3]), bits(oimg[..., :3]))
+    monkeypatch.delenv("PT_NO_FAST_DIV")
+    # odd width: the centre column looks exactly along -z (dir.x == 0, dir.y == 0 for the centre row)
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, width=65, height=37, rays_per_pixel=1,
+                            camera_position=(5.0, 35.0, 150.0), camera_rotation=(0.0, 0.0, 0.0))
+    with r:
+        ids, dist = r.primary_hits()
+    oids, odist = oracle_shared.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
+    assert np.array_equal(ids, oids) and np.array_equal(bits(dist), bits(odist))

@@ -42,6 +42,7 @@ struct pt_ctx {
     PTHitRecord *d_hits = nullptr;
     PTControl *d_ctrl = nullptr;
     float4 *d_samples = nullptr;
+    uint32_t *d_spill = nullptr;
     uint32_t *d_pixel_hit = nullptr;
     float4 *d_pixel_const = nullptr;
     uint32_t max_batch = 1;            /* frames whose samples fit the sample buffer */
@@ -53,6 +54,7 @@ struct pt_ctx {
     uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
+    uint32_t top_count = 0;            /* inner records 0..top_count-1 are the top of the tree (BFS order) */
     bool fast_div = false;
     uint32_t refill_min = 48;
     uint32_t leaf_min = 8;
@@ -184,9 +186,9 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
         uint32_t ha = leaf_a ? 0 : height[f.a];
         uint32_t hb = leaf_b ? 0 : height[f.b];
         PTInnerRecord &r = out.inner[f.rec];
-        r.q[0] = make_float4(na[0], nb[0], na[1], nb[1]);
-        r.q[1] = make_float4(na[2], nb[2], na[3], nb[3]);
-        r.q[2] = make_float4(na[4], nb[4], na[5], nb[5]);
+        r.q[0] = make_float4(na[0], na[1], na[3], na[4]);
+        r.q[1] = make_float4(nb[0], nb[1], nb[3], nb[4]);
+        r.q[2] = make_float4(na[2], na[5], nb[2], nb[5]);
         for (int k = 0; k < 6; k++)
             if (!pt_div_tame_coordinate(na[k]) || !pt_div_tame_coordinate(nb[k])) out.tame_bounds = false;
         float fa, fb;
@@ -200,6 +202,47 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
     out.root_ref = rec_of[0];
     out.depth = height[0];
     return true;
+}
+
+/*
+ * Renumbers the inner records so that the top of the tree comes first in breadth-first order
+ * (the `top_count` records nearest the root get indices 0..top_count-1) and everything below
+ * keeps its depth-first order.  The kernels keep records with index < top_count in LDS.
+ * Only the numbering changes: every record's contents and the visit order are untouched.
+ */
+uint32_t renumber_top_first(Repacked &rp, uint32_t want_top) {
+    const size_t n = rp.inner.size();
+    if (n == 0 || (rp.root_ref & PT_REF_LEAF)) return 0;
+    std::vector<uint32_t> order;                       /* old indices of the top records, BFS */
+    order.reserve(want_top);
+    order.push_back(rp.root_ref);
+    for (size_t head = 0; head < order.size() && order.size() < want_top; head++) {
+        const PTInnerRecord &r = rp.inner[order[head]];
+        uint32_t refs[2];
+        memcpy(&refs[0], &r.q[3].x, 4); memcpy(&refs[1], &r.q[3].y, 4);
+        for (int k = 0; k < 2 && order.size() < want_top; k++) {
+            if (refs[k] & PT_REF_LEAF) continue;
+            bool seen = false;                         /* malformed files may reach a node twice */
+            for (uint32_t o : order) if (o == refs[k]) { seen = true; break; }
+            if (!seen) order.push_back(refs[k]);
+        }
+    }
+    std::vector<uint32_t> new_of(n, 0xffffffffu);
+    for (size_t i = 0; i < order.size(); i++) new_of[order[i]] = (uint32_t)i;
+    uint32_t next = (uint32_t)order.size();
+    for (size_t i = 0; i < n; i++) if (new_of[i] == 0xffffffffu) new_of[i] = next++;
+    std::vector<PTInnerRecord> out(n);
+    for (size_t i = 0; i < n; i++) {
+        PTInnerRecord r = rp.inner[i];
+        uint32_t refs[2];
+        memcpy(&refs[0], &r.q[3].x, 4); memcpy(&refs[1], &r.q[3].y, 4);
+        for (int k = 0; k < 2; k++) if (!(refs[k] & PT_REF_LEAF)) refs[k] = new_of[refs[k]];
+        memcpy(&r.q[3].x, &refs[0], 4); memcpy(&r.q[3].y, &refs[1], 4);
+        out[new_of[i]] = r;
+    }
+    rp.inner.swap(out);
+    rp.root_ref = new_of[rp.root_ref];
+    return (uint32_t)order.size();
 }
 
 void build_tri_records(const float *tris, uint32_t n, std::vector<PTTriRecord> &out) {
@@ -272,6 +315,8 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.use_env = p.use_environment_lighting ? 1u : 0u;
     k.sphere_count = c->sphere_count;
     k.root_ref = c->root_ref;
+    k.stack_entries = (uint32_t)c->stack_entries;
+    k.top_count = c->top_count;
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
     k.leaf_min = c->leaf_min;
@@ -279,6 +324,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
     k.pixel_hit = c->d_pixel_hit; k.pixel_const = c->d_pixel_const;
+    k.spill = c->d_spill; k.spill_stride = pt_lane_stride(c->num_cus);
     k.out_ids = c->d_ids; k.out_dist = c->d_dist; k.counters = c->d_counters;
 }
 
@@ -325,8 +371,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
         PTKernelParams k;
         fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
         HIP_TRY(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(PTControl), c->stream));
-        { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, c->stack_entries, exact, count, false, c->stream)); t.done(); }
-        { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, c->stack_entries, exact, count, c->num_cus, c->stream)); t.done(); }
+        { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream)); t.done(); }
+        { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream)); t.done(); }
         { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
         c->timing.frames += batch;
         c->timing.batches++;
@@ -425,8 +471,8 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     }
     if ((e = hipMalloc(&c->d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pixel_hit)");
     if ((e = hipMalloc(&c->d_pixel_const, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(pixel_const)");
-    if ((e = hipMalloc(&c->d_counters, 16 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
-    if ((e = hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
+    if ((e = hipMalloc(&c->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
+    if ((e = hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
     return PT_OK;
@@ -444,7 +490,10 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     Repacked rp;
     std::string why;
     if (!repack_nodes(bvh, node_count, triangle_count, rp, why)) return fail(c, PT_EINVAL, "malformed BVH file: " + why);
-    int need = (int)rp.depth + 1;            /* array<i32, bvh_max_depth + 1>, shader.wgsl:170 */
+    /* The shader needs array<i32, bvh_max_depth + 1> (shader.wgsl:170).  Here the near child is
+     * never pushed, so at most one entry per level is live: depth entries (at least 1). */
+    int need = rp.depth > 0 ? (int)rp.depth : 1;
+    const uint32_t top_count = 0;
     if (need > pt_max_stack_entries())
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(rp.depth) + " exceeds the supported traversal stack");
     std::vector<PTTriRecord> trec;
@@ -453,7 +502,7 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->scene_loaded = false;
-    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
+    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_spill);
     size_t n_inner = rp.inner.size() ? rp.inner.size() : 1;
     HIP_TRY(c, hipMalloc(&c->d_inner, n_inner * sizeof(PTInnerRecord)));
     if (!rp.inner.empty())
@@ -464,6 +513,10 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     HIP_TRY(c, hipMalloc(&c->d_spheres, n_sph * 12 * sizeof(float)));
     if (sphere_count)
         HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, (size_t)sphere_count * 12 * sizeof(float), hipMemcpyHostToDevice));
+    {   /* overflow area of the path kernel's traversal stacks (only trees deeper than its LDS part) */
+        size_t words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);
+        HIP_TRY(c, hipMalloc(&c->d_spill, (words ? words : 1) * sizeof(uint32_t)));
+    }
     if (rp.big.empty()) rp.big.assign(1, 0);
     HIP_TRY(c, hipMalloc(&c->d_big, rp.big.size() * sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpy(c->d_big, rp.big.data(), rp.big.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -471,6 +524,7 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     c->root_ref = rp.root_ref; c->depth = rp.depth;
     c->inner_count = (uint32_t)rp.inner.size(); c->leaf_count = rp.leaves;
     c->stack_entries = need;
+    c->top_count = top_count;
     c->fast_div = rp.tame_bounds && getenv("PT_NO_FAST_DIV") == nullptr;
     c->scene_loaded = true;
     return PT_OK;
@@ -562,7 +616,7 @@ int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
     if (!c->d_dist) HIP_TRY(c, hipMalloc(&c->d_dist, npix * sizeof(float)));
     PTKernelParams k;
     fill_kernel_params(c, 0, 1, 1, 0, k);
-    HIP_TRY(c, pt_launch_primary(k, c->stack_entries, true, false, true, c->stream));
+    HIP_TRY(c, pt_launch_primary(k, true, false, true, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(prim_id, c->d_ids, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(distance, c->d_dist, npix * sizeof(float), hipMemcpyDeviceToHost));
@@ -595,16 +649,17 @@ int pt_get_debug_stats(pt_ctx *c, uint64_t out[8]) {
     if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long h[16];
+    unsigned long long h[24];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[8 + i];
+    if (getenv("PT_PRINT_TOP")) fprintf(stderr, "top visits: <255 %llu  <511 %llu  <1023 %llu\n", h[16], h[17], h[18]);
     return PT_OK;
 }
 
 int pt_reset_counters(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream));
     return PT_OK;
 }
 
@@ -647,7 +702,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
-    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const);
+    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

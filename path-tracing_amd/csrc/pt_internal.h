@@ -17,11 +17,11 @@
  * holds everything a visit needs: both child boxes and both child references.
  * (The reference reads the two 36-byte child nodes, 72 bytes at 36-byte
  * stride, and then re-reads a child when it is popped.)
- *   q0 = (A.min.x, B.min.x, A.min.y, B.min.y)
- *   q1 = (A.min.z, B.min.z, A.max.x, B.max.x)
- *   q2 = (A.max.y, B.max.y, A.max.z, B.max.z)
+ *   q0 = (A.min.x, A.min.y, A.max.x, A.max.y)
+ *   q1 = (B.min.x, B.min.y, B.max.x, B.max.y)
+ *   q2 = (A.min.z, A.max.z, B.min.z, B.max.z)
  *   q3 = (refA, refB, 0, 0) as raw bits
- * (A and B interleaved so that both boxes are tested with packed-f32 instructions)
+ * (x,y pairs and z pairs feed packed-f32 instructions without register shuffles)
  * Box values are copied verbatim from the file, so ray_box sees the same
  * operands as the shader. */
 struct PTInnerRecord { float4 q[4]; };
@@ -79,6 +79,8 @@ struct PTKernelParams {
     uint32_t use_env;
     uint32_t sphere_count;
     uint32_t root_ref;
+    uint32_t top_count;            /* inner records with index < top_count form the top of the tree, breadth-first */
+    uint32_t stack_entries;        /* LDS traversal stack depth per lane (>= depth of the node file) */
     uint32_t xcd_queues;           /* 1: a block starts on the queue part of the XCD it runs on; 0: blockIdx % 8 */
     uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */
     uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
@@ -90,6 +92,8 @@ struct PTKernelParams {
     float4 *accum;
     PTHitRecord *hits;
     PTControl *ctrl;
+    uint32_t *spill;               /* path kernel: traversal-stack entries beyond the LDS part, entry k of lane g at spill[k*spill_stride + g] */
+    uint32_t spill_stride;
     float4 *samples;               /* radiance of every path, indexed like the queue */
     uint32_t *pixel_hit;           /* per pixel: index into hits, or 0xffffffff when the primary ray missed */
     float4 *pixel_const;           /* per miss pixel: its frame mean (the same in every frame) */
@@ -98,13 +102,15 @@ struct PTKernelParams {
     unsigned long long *counters;  /* 8 words, see flush_counters */
 };
 
-/* launchers implemented in pt_kernels.hip; stack_entries selects the LDS stack size */
-hipError_t pt_launch_primary(const PTKernelParams &kp, int stack_entries, bool exact_math,
+/* launchers implemented in pt_kernels.hip; kp.stack_entries sizes the LDS traversal stacks */
+hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact_math,
                              bool count_work, bool aov_only, hipStream_t stream);
-hipError_t pt_launch_paths(const PTKernelParams &kp, int stack_entries, bool exact_math,
+hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact_math,
                            bool count_work, int num_cus, hipStream_t stream);
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t stream);
 hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t stream);
 int pt_max_stack_entries(void);
+uint32_t pt_lane_stride(int num_cus);   /* upper bound of the path kernel's grid size in lanes */
+uint32_t pt_spill_entries(uint32_t stack_entries);
 
 #endif

@@ -73,7 +73,7 @@ template <bool EXACT> __device__ __forceinline__ float t_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
 }
 
-struct Counters { unsigned long long casts, boxes, tris, paths; };
+struct Counters { unsigned long long casts, boxes, tris, paths; unsigned long long top[3]; };
 
 /* ---- RNG, shader.wgsl:351-375 ---- */
 __device__ __forceinline__ float random_value(uint32_t state) {
@@ -124,16 +124,15 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 
 template <bool FAST>
-__device__ __forceinline__ f2 div2(f2 n, float b, float y) {
+__device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y) {
     if (FAST) {
-        f2 bb = mk2(b, b), yy = mk2(y, y);
-        f2 q = n * yy;
-        f2 r = __builtin_elementwise_fma(-bb, q, n);
-        q = __builtin_elementwise_fma(r, yy, q);
-        r = __builtin_elementwise_fma(-bb, q, n);
-        return __builtin_elementwise_fma(r, yy, q);
+        f2 q = n * y;
+        f2 r = __builtin_elementwise_fma(-b, q, n);
+        q = __builtin_elementwise_fma(r, y, q);
+        r = __builtin_elementwise_fma(-b, q, n);
+        return __builtin_elementwise_fma(r, y, q);
     }
-    return mk2(n.x / b, n.y / b);
+    return mk2(n.x / b.x, n.y / b.y);
 }
 
 __device__ __forceinline__ float box_result(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz) {
@@ -145,18 +144,22 @@ __device__ __forceinline__ float box_result(float tminx, float tminy, float tmin
     return did_hit ? t_near : PT_BOX_MISS;
 }
 
-/* q0 = (A.min.x, B.min.x, A.min.y, B.min.y)  q1 = (A.min.z, B.min.z, A.max.x, B.max.x)
- * q2 = (A.max.y, B.max.y, A.max.z, B.max.z) */
+/* The ray as the box test wants it: x and y ride together in packed instructions, z is
+ * paired with itself (min plane and max plane of one box). */
+struct RayPk { f2 oxy, ozz, dxy, dzz, yxy, yzz; };
+
+/* q0 = (A.min.x, A.min.y, A.max.x, A.max.y)  q1 = (B.min.x, B.min.y, B.max.x, B.max.y)
+ * q2 = (A.min.z, A.max.z, B.min.z, B.max.z) */
 template <bool FAST>
-__device__ __forceinline__ void ray_box2(V3 o, V3 d, V3 y, float4 q0, float4 q1, float4 q2, float &dst_a, float &dst_b) {
-    f2 tminx = div2<FAST>(mk2(q0.x, q0.y) - mk2(o.x, o.x), d.x, y.x);
-    f2 tminy = div2<FAST>(mk2(q0.z, q0.w) - mk2(o.y, o.y), d.y, y.y);
-    f2 tminz = div2<FAST>(mk2(q1.x, q1.y) - mk2(o.z, o.z), d.z, y.z);
-    f2 tmaxx = div2<FAST>(mk2(q1.z, q1.w) - mk2(o.x, o.x), d.x, y.x);
-    f2 tmaxy = div2<FAST>(mk2(q2.x, q2.y) - mk2(o.y, o.y), d.y, y.y);
-    f2 tmaxz = div2<FAST>(mk2(q2.z, q2.w) - mk2(o.z, o.z), d.z, y.z);
-    dst_a = box_result(tminx.x, tminy.x, tminz.x, tmaxx.x, tmaxy.x, tmaxz.x);
-    dst_b = box_result(tminx.y, tminy.y, tminz.y, tmaxx.y, tmaxy.y, tmaxz.y);
+__device__ __forceinline__ void ray_box2(const RayPk &R, float4 q0, float4 q1, float4 q2, float &dst_a, float &dst_b) {
+    f2 a_min = div2<FAST>(mk2(q0.x, q0.y) - R.oxy, R.dxy, R.yxy);
+    f2 a_max = div2<FAST>(mk2(q0.z, q0.w) - R.oxy, R.dxy, R.yxy);
+    f2 b_min = div2<FAST>(mk2(q1.x, q1.y) - R.oxy, R.dxy, R.yxy);
+    f2 b_max = div2<FAST>(mk2(q1.z, q1.w) - R.oxy, R.dxy, R.yxy);
+    f2 a_z = div2<FAST>(mk2(q2.x, q2.y) - R.ozz, R.dzz, R.yzz);
+    f2 b_z = div2<FAST>(mk2(q2.z, q2.w) - R.ozz, R.dzz, R.yzz);
+    dst_a = box_result(a_min.x, a_min.y, a_z.x, a_max.x, a_max.y, a_z.y);
+    dst_b = box_result(b_min.x, b_min.y, b_z.x, b_max.x, b_max.y, b_z.y);
 }
 
 /* may this lane's ray use the reciprocal form?  (scene-side condition: P.fast_div) */
@@ -214,44 +217,84 @@ struct Trav {
     int sp;            /* entries on the LDS stack */
     float best_t;
     int32_t best_id;
-    V3 inv;            /* 1/dir, used by the reciprocal form of ray_box */
+    RayPk R;           /* origin, direction and 1/direction in the layout ray_box2 wants */
 };
 
-__device__ __forceinline__ void trav_begin(const PTKernelParams &P, V3 d, Trav &T) {
+__device__ __forceinline__ void raypk_set(RayPk &R, V3 o, V3 d) {
+    R.oxy = mk2(o.x, o.y); R.ozz = mk2(o.z, o.z);
+    R.dxy = mk2(d.x, d.y); R.dzz = mk2(d.z, d.z);
+    float iz = 1.0f / d.z;
+    R.yxy = mk2(1.0f / d.x, 1.0f / d.y); R.yzz = mk2(iz, iz);
+}
+
+__device__ __forceinline__ V3 ray_origin(const RayPk &R) { return mk(R.oxy.x, R.oxy.y, R.ozz.x); }
+__device__ __forceinline__ V3 ray_dir(const RayPk &R) { return mk(R.dxy.x, R.dxy.y, R.dzz.x); }
+
+/* T.R must hold the ray */
+__device__ __forceinline__ void trav_begin(const PTKernelParams &P, Trav &T) {
     T.cur = P.root_ref;
     T.sp = 0;
     T.best_t = PT_FAR;
     T.best_id = PT_NONE;
-    T.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+}
+
+
+
+/*
+ * Dynamic LDS of both traversal kernels: one traversal stack per lane, stack[wave][entry][lane]
+ * (entries 64 dwords apart, so a wave's pushes and pops never bank-conflict).
+ *
+ * Measured on MI355X and rejected: (1) a copy of the top ~1000 records of the tree in LDS (40 % of
+ * all visits) - no gain; (2) quad-cooperative record fetches through LDS-DMA, which cut the L1 tag
+ * lookups per step by 4 - 20 % slower (longer dependent chain per step); (3) prefetching both
+ * children while the box tests run - 25 % slower.  The traversal is bound by the latency of its
+ * dependent load -> test -> pop chain at the occupancy the register file allows, with the vector
+ * ALU, the vector-memory pipeline and the L1 each about half busy.
+ */
+extern __shared__ uint32_t pt_lds[];
+
+struct WaveMem {
+    uint32_t *stk;          /* this lane's stack column in LDS */
+    uint32_t lds_entries;   /* stack entries kept in LDS; deeper ones go to `spill` */
+    uint32_t *spill;        /* this lane's overflow column in global memory (may be null when unused) */
+    uint32_t spill_stride;
+};
+
+__device__ __forceinline__ void stack_push(const WaveMem &M, Trav &T, uint32_t v) {
+    if ((uint32_t)T.sp < M.lds_entries) M.stk[T.sp * 64] = v;
+    else M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride] = v;
+    T.sp++;
 }
 
 /* after a visit: continue with the near child if one was kept, else pop; true = stack empty */
-__device__ __forceinline__ bool trav_advance(Trav &T, uint32_t *stk) {
+__device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
     if (T.cur != PT_REF_NONE) return false;
     if (T.sp == 0) return true;
     T.sp--;
-    T.cur = stk[T.sp * 64];
+    if ((uint32_t)T.sp < M.lds_entries) T.cur = M.stk[T.sp * 64];
+    else T.cur = M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride];
     return false;
 }
 
 template <bool FAST, bool COUNT>
-__device__ __forceinline__ void inner_visit(const PTKernelParams &P, V3 o, V3 d, Trav &T, uint32_t *stk, Counters &cn) {
+__device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, uint32_t lane, Trav &T, Counters &cn) {
     const PTInnerRecord *rec = P.inner + T.cur;
     float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
     float dst_a, dst_b;
-    ray_box2<FAST>(o, d, T.inv, q0, q1, q2, dst_a, dst_b);
+    ray_box2<FAST>(T.R, q0, q1, q2, dst_a, dst_b);
     if (COUNT) cn.boxes += 2;
     uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
     float dst_near, dst_far;
     uint32_t ref_near, ref_far;
     if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
     else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
-    if (dst_far < T.best_t) { stk[T.sp * 64] = ref_far; T.sp++; }
+    if (dst_far < T.best_t) stack_push(M, T, ref_far);
     T.cur = (dst_near < T.best_t) ? ref_near : PT_REF_NONE;
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void leaf_visit(const PTKernelParams &P, V3 o, V3 d, Trav &T, Counters &cn) {
+__device__ __forceinline__ void leaf_visit(const PTKernelParams &P, Trav &T, Counters &cn) {
+    const V3 o = ray_origin(T.R), d = ray_dir(T.R);
     uint32_t first = T.cur & 0x00ffffffu;
     uint32_t cnt = (T.cur >> 24) & 0x7fu;
     if (cnt == PT_REF_COUNT_ESCAPE) cnt = P.big_leaf_count[first];
@@ -264,37 +307,38 @@ __device__ __forceinline__ void leaf_visit(const PTKernelParams &P, V3 o, V3 d, 
     T.cur = PT_REF_NONE;
 }
 
-/*
- * One step of a whole wave.  Lanes with `traversing` set hold a valid T.cur.  Lanes at an
- * inner node always advance; lanes at a leaf advance only when at least P.leaf_min lanes of
- * the wave are at a leaf or no lane has inner work, otherwise they wait one step with their
- * state untouched.  Waiting changes nothing a lane computes (its own visit order is the
- * shader's); it keeps the triangle code from running for one or two lanes in every step.
- * Returns true for lanes whose traversal completed in this step.
- */
 struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs; };
 
+/*
+ * One step of a whole wave.
+ * Lanes with `traversing` set hold a valid T.cur.  Lanes at an inner node always advance; lanes
+ * at a leaf advance only when at least P.leaf_min lanes of the wave are at a leaf or no lane has
+ * inner work, otherwise they wait one step with their state untouched.  Waiting changes nothing a
+ * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
+ * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
+ */
 template <bool FAST, bool COUNT>
-__device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, bool traversing, V3 o, V3 d, Trav &T,
-                                               uint32_t *stk, Counters &cn, WaveStats *ws = nullptr) {
+__device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, uint32_t lane, bool traversing,
+                                               Trav &T, Counters &cn, WaveStats *ws = nullptr) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
     const bool is_inner = traversing && !is_leaf;
     const unsigned long long inner_mask = __ballot(is_inner);
     const unsigned long long leaf_mask = __ballot(is_leaf);
+    const bool run_leaves = !inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min;
     bool done = false;
     if (COUNT && ws) {
         ws->steps++;
         ws->inner_lanes += (unsigned)__popcll(inner_mask);
-        if (!inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
+        if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
     if (is_inner) {
-        inner_visit<FAST, COUNT>(P, o, d, T, stk, cn);
-        done = trav_advance(T, stk);
+        inner_visit<FAST, COUNT>(P, M, lane, T, cn);
+        done = trav_advance(M, T);
     }
-    if (!inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min) {
+    if (run_leaves) {
         if (is_leaf) {
-            leaf_visit<COUNT>(P, o, d, T, cn);
-            done = trav_advance(T, stk);
+            leaf_visit<COUNT>(P, T, cn);
+            done = trav_advance(M, T);
         }
     }
     return done;
@@ -314,7 +358,7 @@ __device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V
  * index order, then the BVH (which does not see the sphere distance), strict `<`
  * everywhere.  `active` lanes take part; the division form is chosen per wave. */
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const PTKernelParams &P, bool active, V3 o, V3 d, uint32_t *stk,
+__device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveMem &M, uint32_t lane, bool active, V3 o, V3 d,
                                             float &t_out, int32_t &id_out, Counters &cn) {
     float best = PT_FAR;
     int32_t id = PT_NONE;
@@ -323,11 +367,12 @@ __device__ __forceinline__ void closest_hit(const PTKernelParams &P, bool active
         spheres_closest(P, o, d, best, id);
     }
     Trav T;
-    trav_begin(P, d, T);
+    raypk_set(T.R, o, d);
+    trav_begin(P, T);
     bool traversing = active;
     while (__ballot(traversing)) {
-        bool done = fast ? trav_wave_step<true, COUNT>(P, traversing, o, d, T, stk, cn)
-                         : trav_wave_step<false, COUNT>(P, traversing, o, d, T, stk, cn);
+        bool done = fast ? trav_wave_step<true, COUNT>(P, M, lane, traversing, T, cn)
+                         : trav_wave_step<false, COUNT>(P, M, lane, traversing, T, cn);
         if (done) traversing = false;
     }
     if (active) {
@@ -446,23 +491,24 @@ __device__ __forceinline__ void flush_counters(const PTKernelParams &P, const Co
 }
 
 /* ======================= primary rays ======================= */
-template <int STACK, bool EXACT, bool COUNT, bool AOV>
+template <bool EXACT, bool COUNT, bool AOV>
 __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
-    __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *stk = &stack[wave][0][lane];
+    WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
+    M.stk = pt_lds + wave * P.stack_entries * 64u + lane;
+    M.lds_entries = P.stack_entries; M.spill = nullptr; M.spill_stride = 0;
     /* block = 16x16 pixels, wave = 8x8 tile */
     const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
-    Counters cn = {0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, {0, 0, 0}};
 
     V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
     uint32_t pixel_index = 0;
     float t = PT_FAR;
     int32_t id = PT_NONE;
     if (valid) primary_ray(P, px, py, rd, pixel_index);
-    closest_hit<COUNT>(P, valid, ro, rd, stk, t, id, cn);
+    closest_hit<COUNT>(P, M, lane, valid, ro, rd, t, id, cn);
     const uint32_t pixel = py * P.width + px;
     if (AOV) {
         if (valid) { P.out_ids[pixel] = id; P.out_dist[pixel] = t; }
@@ -519,11 +565,13 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_PHASE_DEAD 4      /* queue drained and path finished */
 #define PT_REFILL_MIN 16
 
-template <int STACK, bool EXACT, bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
-    __shared__ uint32_t stack[PT_WAVES_PER_BLOCK][STACK][64];
+template <bool EXACT, bool COUNT>
+__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t *stk = &stack[wave][0][lane];
+    const uint32_t gid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
+    M.stk = pt_lds + wave * lds_entries * 64u + lane;
+    M.lds_entries = lds_entries; M.spill = P.spill + gid; M.spill_stride = P.spill_stride;
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
     const uint32_t total = P.ctrl->hit_count * per_hit;
@@ -531,16 +579,17 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
     /* XCC_ID: bits 3:0 of hardware register 20 */
     uint32_t queue = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
     uint32_t queues_done = 0;
-    Counters cn = {0, 0, 0, 0};
+    Counters cn = {0, 0, 0, 0, {0, 0, 0}};
 
     int phase = PT_PHASE_IDLE;
     bool drained = total == 0;
     uint32_t item = 0, seed = 0, i = 0;
-    V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
-    Trav T;
-    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = PT_FAR; T.best_id = PT_NONE; T.inv = mk(0, 0, 0);
+    V3 light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
     float sph_t = PT_FAR;
     int32_t sph_id = PT_NONE;
+    Trav T;      /* T.R is the lane's current ray: the only copy kept across the traversal loop */
+    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = PT_FAR; T.best_id = PT_NONE;
+    raypk_set(T.R, mk(0, 0, 0), mk(0, 0, -1));
     bool safe = false;
     WaveStats ws = {0, 0, 0, 0};
     unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0;
@@ -552,6 +601,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
         if (phase == PT_PHASE_HIT) {
             float t = sph_t;
             int32_t id = sph_id;
+            V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
             if (T.best_id != PT_NONE && T.best_t < t) { t = T.best_t; id = T.best_id; }
             bool finished;
             if (id != PT_NONE) {
@@ -567,6 +617,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
                 P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
                 phase = PT_PHASE_IDLE;
             } else {
+                raypk_set(T.R, ro, rd);
                 phase = PT_PHASE_RAY;
             }
         }
@@ -597,8 +648,8 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
                         uint32_t py = fast_div(h.pixel, P.div_width);
                         uint32_t px = h.pixel - py * P.width;
                         uint32_t pixel_index;
+                        V3 ro = ld3(P.cam_pos), rd;
                         primary_ray(P, px, py, rd, pixel_index);
-                        ro = ld3(P.cam_pos);
                         /* shader.wgsl:100 and :121, folded: the frame term is the same for every bounce */
                         seed = pixel_index + s * 248135u + frame_count * 393939123u;
                         light = mk(0.0f, 0.0f, 0.0f);
@@ -609,6 +660,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
                         if (i > P.max_bounce_count) {                           /* max_bounce_count == 0 */
                             P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
                         } else {
+                            raypk_set(T.R, ro, rd);
                             phase = PT_PHASE_RAY;
                         }
                     }
@@ -623,8 +675,9 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
         }
         /* (C) new rays: spheres first (shader.wgsl:144-154), then set up the traversal */
         if (phase == PT_PHASE_RAY) {
+            V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
             spheres_closest(P, ro, rd, sph_t, sph_id);
-            trav_begin(P, rd, T);
+            trav_begin(P, T);
             safe = ray_div_safe(ro, rd);
             if (COUNT) cn.casts++;
             phase = PT_PHASE_TRAV;
@@ -640,8 +693,8 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
             unsigned long long waiting = __ballot(phase == PT_PHASE_HIT);
             if ((uint32_t)__popcll(waiting) >= P.refill_min) break;
             const bool traversing = phase == PT_PHASE_TRAV;
-            bool done = fast ? trav_wave_step<true, COUNT>(P, traversing, ro, rd, T, stk, cn, &ws)
-                             : trav_wave_step<false, COUNT>(P, traversing, ro, rd, T, stk, cn, &ws);
+            bool done = fast ? trav_wave_step<true, COUNT>(P, M, lane, traversing, T, cn, &ws)
+                             : trav_wave_step<false, COUNT>(P, M, lane, traversing, T, cn, &ws);
             if (done) phase = PT_PHASE_HIT;
         }
         if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
@@ -658,6 +711,10 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P) {
             atomicAdd(&P.counters[13], ws.leaf_runs);
             atomicAdd(&P.counters[14], outer_iters);
             atomicAdd(&P.counters[15], shade_lanes);
+        }
+        {
+            unsigned long long a = wave_sum(cn.top[0]), b2 = wave_sum(cn.top[1]), c2 = wave_sum(cn.top[2]);
+            if (lane == 0) { atomicAdd(&P.counters[16], a); atomicAdd(&P.counters[17], b2); atomicAdd(&P.counters[18], c2); }
         }
     }
 }
@@ -699,68 +756,56 @@ __global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, f
 }
 
 /* ======================= launchers ======================= */
-static const int kStackSizes[] = {24, 32, 48, 64};
-int pt_max_stack_entries(void) { return 64; }
+int pt_max_stack_entries(void) { return 64; }       /* 64 entries x 4 waves x 256 B = 64 KiB, the default dynamic-LDS limit */
+/* the persistent grid never exceeds 8 blocks per CU */
+uint32_t pt_lane_stride(int num_cus) { return (uint32_t)num_cus * 8u * PT_BLOCK; }
 
-template <int STACK>
-static hipError_t launch_primary_s(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
+#define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS */
+
+static size_t block_lds_bytes(uint32_t entries) {
+    return (size_t)PT_WAVES_PER_BLOCK * (size_t)entries * 64 * sizeof(uint32_t);
+}
+
+/* stack entries per lane the path kernel spills to global memory, for sizing PTKernelParams::spill */
+uint32_t pt_spill_entries(uint32_t stack_entries) {
+    return stack_entries > PT_PATH_LDS_STACK ? stack_entries - PT_PATH_LDS_STACK : 0;
+}
+
+hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
+    if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
     dim3 grid((kp.width + 15) / 16, (kp.height + 15) / 16), block(PT_BLOCK);
+    const size_t lds = block_lds_bytes(kp.stack_entries);
     if (aov) {
-        hipLaunchKernelGGL((primary_kernel<STACK, true, false, true>), grid, block, 0, st, kp);
+        hipLaunchKernelGGL((primary_kernel<true, false, true>), grid, block, lds, st, kp);
     } else if (count) {
-        if (exact) hipLaunchKernelGGL((primary_kernel<STACK, true, true, false>), grid, block, 0, st, kp);
-        else       hipLaunchKernelGGL((primary_kernel<STACK, false, true, false>), grid, block, 0, st, kp);
+        if (exact) hipLaunchKernelGGL((primary_kernel<true, true, false>), grid, block, lds, st, kp);
+        else       hipLaunchKernelGGL((primary_kernel<false, true, false>), grid, block, lds, st, kp);
     } else {
-        if (exact) hipLaunchKernelGGL((primary_kernel<STACK, true, false, false>), grid, block, 0, st, kp);
-        else       hipLaunchKernelGGL((primary_kernel<STACK, false, false, false>), grid, block, 0, st, kp);
+        if (exact) hipLaunchKernelGGL((primary_kernel<true, false, false>), grid, block, lds, st, kp);
+        else       hipLaunchKernelGGL((primary_kernel<false, false, false>), grid, block, lds, st, kp);
     }
     return hipGetLastError();
 }
 
-template <int STACK>
-static hipError_t launch_paths_s(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
-    /* persistent grid: enough blocks to fill every CU for the LDS the stack needs */
-    size_t lds = (size_t)PT_WAVES_PER_BLOCK * STACK * 64 * 4;
-    int per_cu = (int)((160 * 1024) / lds);
+hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
+    if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
+    /* persistent grid: as many 4-wave blocks per CU as stay resident (8 at most) */
+    uint32_t lds_entries = kp.stack_entries < PT_PATH_LDS_STACK ? kp.stack_entries : PT_PATH_LDS_STACK;
+    if (const char *e = getenv("PT_LDS_STACK")) { int v = atoi(e); if (v >= 1 && (uint32_t)v <= kp.stack_entries && v >= PT_PATH_LDS_STACK) lds_entries = (uint32_t)v; }
+    const size_t lds = block_lds_bytes(lds_entries);
+    int per_cu = (int)((160 * 1024 - 512) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu), block(PT_BLOCK);
     if (count) {
-        if (exact) hipLaunchKernelGGL((path_kernel<STACK, true, true>), grid, block, 0, st, kp);
-        else       hipLaunchKernelGGL((path_kernel<STACK, false, true>), grid, block, 0, st, kp);
+        if (exact) hipLaunchKernelGGL((path_kernel<true, true>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, true>), grid, block, lds, st, kp, lds_entries);
     } else {
-        if (exact) hipLaunchKernelGGL((path_kernel<STACK, true, false>), grid, block, 0, st, kp);
-        else       hipLaunchKernelGGL((path_kernel<STACK, false, false>), grid, block, 0, st, kp);
+        if (exact) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds, st, kp, lds_entries);
     }
     return hipGetLastError();
-}
-
-static int pick_stack(int need) {
-    for (int s : kStackSizes) if (need <= s) return s;
-    return -1;
-}
-
-hipError_t pt_launch_primary(const PTKernelParams &kp, int stack_entries, bool exact, bool count,
-                             bool aov, hipStream_t st) {
-    switch (pick_stack(stack_entries)) {
-        case 24: return launch_primary_s<24>(kp, exact, count, aov, st);
-        case 32: return launch_primary_s<32>(kp, exact, count, aov, st);
-        case 48: return launch_primary_s<48>(kp, exact, count, aov, st);
-        case 64: return launch_primary_s<64>(kp, exact, count, aov, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-hipError_t pt_launch_paths(const PTKernelParams &kp, int stack_entries, bool exact, bool count,
-                           int num_cus, hipStream_t st) {
-    switch (pick_stack(stack_entries)) {
-        case 24: return launch_paths_s<24>(kp, exact, count, num_cus, st);
-        case 32: return launch_paths_s<32>(kp, exact, count, num_cus, st);
-        case 48: return launch_paths_s<48>(kp, exact, count, num_cus, st);
-        case 64: return launch_paths_s<64>(kp, exact, count, num_cus, st);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t st) {

@@ -1,0 +1,66 @@
+"""Two processes, one MI355X: the frame-sharded render path (ShardedRenderer: torch tensor bound as
+accumulation buffer, pt_render_frames_sum, all-reduce, scale) end to end on the GPU.  The box has a
+single GPU, so the two ranks share it and the process group uses gloo (RCCL refuses two ranks on one
+device); bench.py --gpus N runs the same code with backend nccl, one rank per GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import ShardedRenderer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = pkg.default_params(width=96, height=54, rays_per_pixel=2, max_bounce_count=3, flags=pkg.PT_FLAG_EXACT_MATH)
+    with pkg.Renderer(p, device=0) as r:
+        r.upload_scene(scenes.spheres_for("cfg1"), tris, bvh)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        sh = ShardedRenderer(r, rank, world)
+        sh.render(0, n_frames)
+        sh.render(0, n_frames)          # a second render must start from a clean buffer
+        img = sh.image().cpu().numpy()
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu(tmp_path, oracle_shared, scenes):
+    import torch.multiprocessing as mp
+    n_frames = 5
+    mp.spawn(_worker, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=96, height=54, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    parts = [oracle_shared.render_frames_sum(p, sc, cam, rot, rank, len(range(rank, n_frames, 2)), 2) for rank in range(2)]
+    want = (parts[0] + parts[1]) * np.float32(1.0 / n_frames)
+    assert np.array_equal(r0[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+    mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
+    np.testing.assert_allclose(r0[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)

@@ -21,6 +21,7 @@
 #ifndef PT_API_H
 #define PT_API_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -204,6 +205,23 @@ const char *pt_last_error(pt_ctx *ctx);
 int pt_bvh_build(const float *triangles_in, uint32_t triangle_count, int max_depth,
                  float *triangles_out, float **nodes_out, uint32_t *node_count);
 void pt_free(void *p);
+
+/*
+ * ASCII STL -> .bin converter, replaces prepare_data/data_formatter.js:9-18.
+ * Every line containing "vertex" contributes the numbers that follow its first
+ * "vertex " (split at single spaces, JavaScript Number() rules: an empty piece
+ * is 0, a non-number is NaN), each multiplied by `scale` in double precision
+ * (data_formatter.js:5) and rounded once to f32.  *out is allocated by the
+ * library (free with pt_free) and holds *n_floats values, 9 per triangle for a
+ * well-formed file; like the script, nothing here checks that count.  A line
+ * with "vertex" but without "vertex " makes the script throw: PT_EINVAL here.
+ * pt_stl_format_file reads stl_path and writes the values as little-endian f32
+ * to bin_path (data_formatter.js:15-18).  Pure host code.
+ */
+int pt_stl_format(const char *stl_text, size_t length, double scale, float **out, uint64_t *n_floats);
+int pt_stl_format_file(const char *stl_path, const char *bin_path, double scale, uint64_t *n_floats);
+/* Message of the calling thread's last failed pt_stl_format* call. */
+const char *pt_stl_format_error(void);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ API_SYMBOLS = [
     "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
+    "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
 ]
 
 
@@ -122,6 +123,10 @@ def load_library():
     L.pt_bvh_build.argtypes = [fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32)]
     L.pt_free.argtypes = [C.c_void_p]
     L.pt_free.restype = None
+    L.pt_stl_format.argtypes = [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(fp), C.POINTER(C.c_uint64)]
+    L.pt_stl_format_file.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.POINTER(C.c_uint64)]
+    L.pt_stl_format_error.argtypes = []
+    L.pt_stl_format_error.restype = C.c_char_p
     _lib = L
     return L
 
@@ -163,6 +168,31 @@ def bvh_build(triangles, max_depth):
     nodes = np.ctypeslib.as_array(nodes_p, shape=(n.value, 9)).copy()
     L.pt_free(nodes_p)
     return out_tr, nodes
+
+
+def stl_format(stl_text, scale=1.0):
+    """ASCII STL text (bytes or str) -> flat f32 array, 9 values per triangle
+    (prepare_data/data_formatter.js:9-18)."""
+    L = load_library()
+    data = stl_text.encode("utf-8") if isinstance(stl_text, str) else bytes(stl_text)
+    out_p = C.POINTER(C.c_float)()
+    n = C.c_uint64()
+    rc = L.pt_stl_format(data, len(data), float(scale), C.byref(out_p), C.byref(n))
+    if rc:
+        raise PtError(rc, L.pt_stl_format_error().decode())
+    out = np.ctypeslib.as_array(out_p, shape=(n.value,)).copy() if n.value else np.zeros(0, np.float32)
+    L.pt_free(out_p)
+    return out
+
+
+def stl_format_file(stl_path, bin_path, scale=1.0):
+    """Writes bin_path from stl_path; returns the number of f32 values written."""
+    L = load_library()
+    n = C.c_uint64()
+    rc = L.pt_stl_format_file(os.fsencode(stl_path), os.fsencode(bin_path), float(scale), C.byref(n))
+    if rc:
+        raise PtError(rc, L.pt_stl_format_error().decode())
+    return n.value
 
 
 class Renderer:

@@ -54,7 +54,6 @@ struct pt_ctx {
     uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
-    uint32_t top_count = 0;            /* inner records 0..top_count-1 are the top of the tree (BFS order) */
     bool fast_div = false;
     uint32_t refill_min = 48;
     uint32_t leaf_min = 8;
@@ -204,47 +203,6 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
     return true;
 }
 
-/*
- * Renumbers the inner records so that the top of the tree comes first in breadth-first order
- * (the `top_count` records nearest the root get indices 0..top_count-1) and everything below
- * keeps its depth-first order.  The kernels keep records with index < top_count in LDS.
- * Only the numbering changes: every record's contents and the visit order are untouched.
- */
-uint32_t renumber_top_first(Repacked &rp, uint32_t want_top) {
-    const size_t n = rp.inner.size();
-    if (n == 0 || (rp.root_ref & PT_REF_LEAF)) return 0;
-    std::vector<uint32_t> order;                       /* old indices of the top records, BFS */
-    order.reserve(want_top);
-    order.push_back(rp.root_ref);
-    for (size_t head = 0; head < order.size() && order.size() < want_top; head++) {
-        const PTInnerRecord &r = rp.inner[order[head]];
-        uint32_t refs[2];
-        memcpy(&refs[0], &r.q[3].x, 4); memcpy(&refs[1], &r.q[3].y, 4);
-        for (int k = 0; k < 2 && order.size() < want_top; k++) {
-            if (refs[k] & PT_REF_LEAF) continue;
-            bool seen = false;                         /* malformed files may reach a node twice */
-            for (uint32_t o : order) if (o == refs[k]) { seen = true; break; }
-            if (!seen) order.push_back(refs[k]);
-        }
-    }
-    std::vector<uint32_t> new_of(n, 0xffffffffu);
-    for (size_t i = 0; i < order.size(); i++) new_of[order[i]] = (uint32_t)i;
-    uint32_t next = (uint32_t)order.size();
-    for (size_t i = 0; i < n; i++) if (new_of[i] == 0xffffffffu) new_of[i] = next++;
-    std::vector<PTInnerRecord> out(n);
-    for (size_t i = 0; i < n; i++) {
-        PTInnerRecord r = rp.inner[i];
-        uint32_t refs[2];
-        memcpy(&refs[0], &r.q[3].x, 4); memcpy(&refs[1], &r.q[3].y, 4);
-        for (int k = 0; k < 2; k++) if (!(refs[k] & PT_REF_LEAF)) refs[k] = new_of[refs[k]];
-        memcpy(&r.q[3].x, &refs[0], 4); memcpy(&r.q[3].y, &refs[1], 4);
-        out[new_of[i]] = r;
-    }
-    rp.inner.swap(out);
-    rp.root_ref = new_of[rp.root_ref];
-    return (uint32_t)order.size();
-}
-
 void build_tri_records(const float *tris, uint32_t n, std::vector<PTTriRecord> &out) {
     out.resize(n ? n : 1);
     for (uint32_t i = 0; i < n; i++) {
@@ -316,7 +274,6 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.sphere_count = c->sphere_count;
     k.root_ref = c->root_ref;
     k.stack_entries = (uint32_t)c->stack_entries;
-    k.top_count = c->top_count;
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
     k.leaf_min = c->leaf_min;
@@ -493,7 +450,6 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     /* The shader needs array<i32, bvh_max_depth + 1> (shader.wgsl:170).  Here the near child is
      * never pushed, so at most one entry per level is live: depth entries (at least 1). */
     int need = rp.depth > 0 ? (int)rp.depth : 1;
-    const uint32_t top_count = 0;
     if (need > pt_max_stack_entries())
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(rp.depth) + " exceeds the supported traversal stack");
     std::vector<PTTriRecord> trec;
@@ -524,7 +480,6 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     c->root_ref = rp.root_ref; c->depth = rp.depth;
     c->inner_count = (uint32_t)rp.inner.size(); c->leaf_count = rp.leaves;
     c->stack_entries = need;
-    c->top_count = top_count;
     c->fast_div = rp.tame_bounds && getenv("PT_NO_FAST_DIV") == nullptr;
     c->scene_loaded = true;
     return PT_OK;
@@ -652,7 +607,6 @@ int pt_get_debug_stats(pt_ctx *c, uint64_t out[8]) {
     unsigned long long h[24];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[8 + i];
-    if (getenv("PT_PRINT_TOP")) fprintf(stderr, "top visits: <255 %llu  <511 %llu  <1023 %llu\n", h[16], h[17], h[18]);
     return PT_OK;
 }
 

@@ -79,7 +79,6 @@ struct PTKernelParams {
     uint32_t use_env;
     uint32_t sphere_count;
     uint32_t root_ref;
-    uint32_t top_count;            /* inner records with index < top_count form the top of the tree, breadth-first */
     uint32_t stack_entries;        /* LDS traversal stack depth per lane (>= depth of the node file) */
     uint32_t xcd_queues;           /* 1: a block starts on the queue part of the XCD it runs on; 0: blockIdx % 8 */
     uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */

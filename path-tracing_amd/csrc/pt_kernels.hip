@@ -73,7 +73,7 @@ template <bool EXACT> __device__ __forceinline__ float t_pow(float x, float y) {
     return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
 }
 
-struct Counters { unsigned long long casts, boxes, tris, paths; unsigned long long top[3]; };
+struct Counters { unsigned long long casts, boxes, tris, paths; };
 
 /* ---- RNG, shader.wgsl:351-375 ---- */
 __device__ __forceinline__ float random_value(uint32_t state) {
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
     const bool valid = px < P.width && py < P.height;
-    Counters cn = {0, 0, 0, 0, {0, 0, 0}};
+    Counters cn = {0, 0, 0, 0};
 
     V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
     uint32_t pixel_index = 0;
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
     /* XCC_ID: bits 3:0 of hardware register 20 */
     uint32_t queue = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
     uint32_t queues_done = 0;
-    Counters cn = {0, 0, 0, 0, {0, 0, 0}};
+    Counters cn = {0, 0, 0, 0};
 
     int phase = PT_PHASE_IDLE;
     bool drained = total == 0;
@@ -711,10 +711,6 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
             atomicAdd(&P.counters[13], ws.leaf_runs);
             atomicAdd(&P.counters[14], outer_iters);
             atomicAdd(&P.counters[15], shade_lanes);
-        }
-        {
-            unsigned long long a = wave_sum(cn.top[0]), b2 = wave_sum(cn.top[1]), c2 = wave_sum(cn.top[2]);
-            if (lane == 0) { atomicAdd(&P.counters[16], a); atomicAdd(&P.counters[17], b2); atomicAdd(&P.counters[18], c2); }
         }
     }
 }

@@ -233,3 +233,71 @@ def test_slow_division_path_agrees(pkg, scenes, oracle_shared, monkeypatch):
         ids, dist = r.primary_hits()
     oids, odist = oracle_shared.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
     assert np.array_equal(ids, oids) and np.array_equal(bits(dist), bits(odist))
+
+
+def _comb_scene(n, seed=7):
+    """n triangles perpendicular to z, one behind the other, in a degenerate "comb" BVH: every
+    inner node has a one-triangle leaf and the rest of the chain as children, so the tree is
+    n - 1 levels deep and a ray from +z pushes one entry per level."""
+    rng = np.random.default_rng(seed)
+    tris = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        s = 3.0 + 2.0 * rng.random()
+        ox, oy = rng.uniform(-0.5, 0.5, 2)
+        z = 0.5 * i
+        tris[i] = [ox - s, oy - s, z, ox + s, oy - s, z, ox, oy + s, z]      # faces +z
+    v = tris.reshape(n, 3, 3)
+    nodes = []
+
+    def bounds(lo, hi):
+        p = v[lo:hi].reshape(-1, 3)
+        return list(p.min(axis=0)) + list(p.max(axis=0))
+
+    for i in range(n - 1):
+        nodes.append(bounds(i, n) + [i, n - i, len(nodes) + 1])               # inner: children follow
+        nodes.append(bounds(i, i + 1) + [i, 1, 0])                            # leaf: triangle i
+    nodes.append(bounds(n - 1, n) + [n - 1, 1, 0])
+    return tris, np.asarray(nodes, np.float32)
+
+
+@pytest.mark.parametrize("n", [12, 40, 64])
+def test_deep_tree_uses_the_stack_overflow_area(pkg, oracle_shared, orc_mod, n):
+    """Trees deeper than the part of the traversal stack kept in LDS (16 entries) continue in
+    global memory; 64 levels is the deepest tree accepted.  Ids, distances, radiance and work
+    counters must still be the oracle's."""
+    tris, bvh = _comb_scene(n)
+    cam, rot = (0.3, 0.2, 0.5 * n + 12.0), (1.5, -2.0, 0.0)
+    # a big glossy sphere behind the camera sends the first bounce back into the comb, so the
+    # path kernel (not only the primary kernel) walks the whole depth
+    spheres = np.asarray([[0.0, 0.0, 0.5 * n + 80.0, 50.0, 0.9, 0.8, 0.7, 0.0, 0.0, 0.0, 0.0, 0.95]], np.float32)
+    kw = dict(width=96, height=54, rays_per_pixel=2, max_bounce_count=3)
+    r = pkg.Renderer(pkg.default_params(flags=pkg.PT_FLAG_EXACT_MATH | pkg.PT_FLAG_COUNT_WORK, **kw), device=0)
+    with r:
+        r.upload_scene(spheres, tris, bvh)
+        assert r.scene_info()["bvh_depth"] == n - 1
+        r.set_camera(cam, rot)
+        ids, dist = r.primary_hits()
+        r.reset_counters()
+        r.render(2)
+        img = r.read_accum(4)
+        got = r.counters()
+    op = oracle_shared.default_params(**kw)
+    sc = oracle_shared.scene(spheres, tris, bvh)
+    oids, odist = oracle_shared.primary_hits(op, sc, cam, rot)
+    assert (ids != pkg.MISS_ID).mean() > 0.2 and len(np.unique(ids)) >= 3
+    assert np.array_equal(ids, oids) and np.array_equal(bits(dist), bits(odist))
+    c = orc_mod.OrcCounters()
+    oimg = oracle_shared.render_frames(op, sc, cam, rot, 0, 2, counters=c)
+    assert np.array_equal(bits(img[..., :3]), bits(oimg[..., :3]))
+    want = c.as_dict()
+    assert c.max_stack >= n - 1
+    for k in ("ray_casts", "box_tests", "tri_tests", "paths"):
+        assert got[k] == want[k], k
+
+
+def test_tree_deeper_than_the_stack_is_rejected(pkg):
+    tris, bvh = _comb_scene(70)
+    r = pkg.Renderer(pkg.default_params(width=32, height=32), device=0)
+    with r:
+        with pytest.raises(pkg.PtError):
+            r.upload_scene(np.zeros((0, 12), np.float32), tris, bvh)

@@ -301,3 +301,31 @@ def test_tree_deeper_than_the_stack_is_rejected(pkg):
     with r:
         with pytest.raises(pkg.PtError):
             r.upload_scene(np.zeros((0, 12), np.float32), tris, bvh)
+
+
+@pytest.mark.parametrize("n,step", [(4, 40), (5, 60), (3, 24)])
+def test_full_size_configs_on_a_pixel_lattice(pkg, scenes, oracle_shared, n, step):
+    """The benchmark workloads at their full resolution, rays per pixel and bounce count (config 4
+    is what bench.py times; config 5 is 4K with 16 spheres and 12 bounces): two frames on the GPU,
+    every `step`-th pixel in x and y recomputed by the oracle, bit-exact in exact-math mode.
+    Whole-buffer properties at this size: rendering the two frames in one call or in two calls
+    gives the same bits, and every pixel is finite."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, n, flags=pkg.PT_FLAG_EXACT_MATH)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    W, H = cfg["width"], cfg["height"]
+    with r:
+        r.render_frames(0, 2)
+        img = r.read_accum(4)
+        r.render_frames(0, 1)
+        r.render_frames(1, 1)
+        img2 = r.read_accum(4)
+    assert np.array_equal(bits(img), bits(img2))
+    assert np.isfinite(img).all()
+    acc = np.zeros((H, W, 4), np.float32)
+    x0, y0 = step // 2, step // 3
+    for f in range(2):
+        oracle_shared.render_frame_region(op, sc, cam, rot, f, acc, x0, W, step, y0, H, step)
+    got, want = img[y0::step, x0::step, :3], acc[y0::step, x0::step, :3]
+    assert want.shape[0] * want.shape[1] > 1000
+    assert (want.sum(axis=-1) > 0).mean() > 0.5
+    assert np.array_equal(bits(got), bits(want))

@@ -418,8 +418,11 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     {
         size_t budget = (size_t)12 << 30;
         if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
-        size_t per_frame = npix * params->rays_per_pixel * sizeof(float4);
+        /* hit pixels are stored in interleaved groups of 64; slot numbers are 32-bit */
+        size_t slots_per_frame = ((npix + 63) / 64 * 64) * params->rays_per_pixel;
+        size_t per_frame = slots_per_frame * sizeof(float4);
         size_t nb = budget / per_frame;
+        if (nb > 0xffffffffull / slots_per_frame) nb = 0xffffffffull / slots_per_frame;
         if (nb < 1) nb = 1;
         if (nb > 64) nb = 64;
         if (const char *ev = getenv("PT_MAX_BATCH")) { long v = atol(ev); if (v >= 1 && (size_t)v < nb) nb = (size_t)v; }

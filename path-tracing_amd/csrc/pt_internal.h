@@ -93,7 +93,7 @@ struct PTKernelParams {
     PTControl *ctrl;
     uint32_t *spill;               /* path kernel: traversal-stack entries beyond the LDS part, entry k of lane g at spill[k*spill_stride + g] */
     uint32_t spill_stride;
-    float4 *samples;               /* radiance of every path, indexed like the queue */
+    float4 *samples;               /* radiance of every path; 64 hit pixels interleaved (sample_slot) */
     uint32_t *pixel_hit;           /* per pixel: index into hits, or 0xffffffff when the primary ray missed */
     float4 *pixel_const;           /* per miss pixel: its frame mean (the same in every frame) */
     int32_t *out_ids;

@@ -460,6 +460,13 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, PTFastDiv f) {
     return (t + ((n - t) >> f.sh1)) >> f.sh2;
 }
 
+/* Where sample `fs` (= frame of the batch * rays_per_pixel + sample) of hit pixel `hit` lives:
+ * 64 hit pixels are interleaved, so that the resolve kernel, one lane per hit pixel, reads
+ * consecutive 16-byte values across a wave. */
+__device__ __forceinline__ uint32_t sample_slot(uint32_t hit, uint32_t fs, uint32_t per_hit) {
+    return ((hit >> 6) * per_hit + fs) * 64u + (hit & 63u);
+}
+
 __device__ __forceinline__ uint32_t lane_id() {
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
 
     int phase = PT_PHASE_IDLE;
     bool drained = total == 0;
-    uint32_t item = 0, seed = 0, i = 0;
+    uint32_t slot = 0, seed = 0, i = 0;
     V3 light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
     float sph_t = PT_FAR;
     int32_t sph_id = PT_NONE;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
                 finished = true;
             }
             if (finished) {
-                P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
+                P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                 phase = PT_PHASE_IDLE;
             } else {
                 raypk_set(T.R, ro, rd);
@@ -637,12 +644,13 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
                 if (base < q_len && phase == PT_PHASE_IDLE) {
                     const uint32_t local = base + prefix_count(need);
                     if (local < q_len) {
-                        item = q_start + local;
+                        const uint32_t item = q_start + local;
                         /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
                         /* queue index -> (hit pixel, frame of the batch, sample) */
                         uint32_t hf = fast_div(item, P.div_rpp);
                         uint32_t s = item - hf * rpp;
                         uint32_t hi = fast_div(hf, P.div_batch);
+                        slot = sample_slot(hi, item - hi * per_hit, per_hit);
                         uint32_t frame_count = P.frame_first + (hf - hi * P.batch_frames) * P.frame_stride;
                         PTHitRecord h = P.hits[hi];
                         uint32_t py = fast_div(h.pixel, P.div_width);
@@ -658,7 +666,7 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
                         bounce<EXACT>(P, sf, seed, 0u, ro, rd, light, ray_color);
                         i = 1;
                         if (i > P.max_bounce_count) {                           /* max_bounce_count == 0 */
-                            P.samples[item] = make_float4(light.x, light.y, light.z, 0.0f);
+                            P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                         } else {
                             raypk_set(T.R, ro, rd);
                             phase = PT_PHASE_RAY;
@@ -716,32 +724,39 @@ __global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32
 }
 
 /* ======================= per-pixel resolve ======================= */
-/* One thread per pixel: folds the frames of the batch into the accumulation buffer in frame
- * order (shader.wgsl:99-106): per frame the samples are added in sample order, divided by
- * rays_per_pixel and blended with weight 1/(frame_count+1).  One read-modify-write of the
- * pixel per batch. */
+/* Folds the frames of the batch into the accumulation buffer in frame order (shader.wgsl:99-106):
+ * per frame the samples are added in sample order, divided by rays_per_pixel and blended with
+ * weight 1/(frame_count+1).  One read-modify-write of a pixel per batch.  Thread t finishes hit
+ * pixel number t of the hit list (its samples are interleaved with those of the 63 other hit
+ * pixels of its wave, see sample_slot) and, independently, pixel t of the image if that is a miss
+ * pixel; every pixel is written by exactly one thread. */
 __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
-    const uint32_t pixel = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pixel >= P.width * P.height) return;
-    const uint32_t h = P.pixel_hit[pixel];
-    float4 a4 = P.accum[pixel];
-    V3 acc = mk(a4.x, a4.y, a4.z);
-    if (h == 0xffffffffu) {
-        float4 c = P.pixel_const[pixel];
-        for (uint32_t b = 0; b < P.batch_frames; b++)
-            acc = fold_frame(P, acc, mk(c.x, c.y, c.z), P.frame_first + b * P.frame_stride);
-    } else {
-        const float4 *s = P.samples + (size_t)h * P.batch_frames * P.rays_per_pixel;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rpp = P.rays_per_pixel, per_hit = P.batch_frames * rpp;
+    if (t < P.ctrl->hit_count) {
+        const uint32_t pixel = P.hits[t].pixel;
+        float4 a4 = P.accum[pixel];
+        V3 acc = mk(a4.x, a4.y, a4.z);
+        const float4 *s = P.samples + (size_t)sample_slot(t, 0u, per_hit);
         for (uint32_t b = 0; b < P.batch_frames; b++) {
             V3 sum = mk(0.0f, 0.0f, 0.0f);
-            for (uint32_t k = 0; k < P.rays_per_pixel; k++) {          /* shader.wgsl:99-101, in sample order */
-                float4 v = s[b * P.rays_per_pixel + k];
+#pragma unroll 4
+            for (uint32_t k = 0; k < rpp; k++) {          /* shader.wgsl:99-101, in sample order */
+                float4 v = s[(size_t)(b * rpp + k) * 64u];
                 sum = sum + mk(v.x, v.y, v.z);
             }
             acc = fold_frame(P, acc, sum, P.frame_first + b * P.frame_stride);
         }
+        P.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     }
-    P.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (t < P.width * P.height && P.pixel_hit[t] == 0xffffffffu) {
+        float4 a4 = P.accum[t];
+        V3 acc = mk(a4.x, a4.y, a4.z);
+        float4 c = P.pixel_const[t];
+        for (uint32_t b = 0; b < P.batch_frames; b++)
+            acc = fold_frame(P, acc, mk(c.x, c.y, c.z), P.frame_first + b * P.frame_stride);
+        P.accum[t] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    }
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, float s) {

@@ -55,8 +55,9 @@ struct pt_ctx {
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
     bool fast_div = false;
-    uint32_t refill_min = 48;
+    uint32_t refill_min = 58;
     uint32_t leaf_min = 8;
+    uint32_t leaf_shift = 2;
 
     std::vector<EventPair> pending;    /* recorded, not yet read */
     std::vector<EventPair> free_events;
@@ -277,6 +278,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
     k.leaf_min = c->leaf_min;
+    k.leaf_shift = c->leaf_shift;
     k.xcd_queues = getenv("PT_NO_XCD_QUEUES") ? 0u : 1u;
     k.inner = c->d_inner; k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
@@ -395,6 +397,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->device = device_ordinal;
     c->params = *params;
     if (const char *e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_min = (uint32_t)v; }
+    if (const char *e = getenv("PT_LEAF_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 6) c->leaf_shift = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }
     auto bail = [&](hipError_t he, const char *what) {
         int r = fail_hip(nullptr, he, what);

@@ -82,6 +82,7 @@ struct PTKernelParams {
     uint32_t stack_entries;        /* LDS traversal stack depth per lane (>= depth of the node file) */
     uint32_t xcd_queues;           /* 1: a block starts on the queue part of the XCD it runs on; 0: blockIdx % 8 */
     uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */
+    uint32_t leaf_shift;           /* ... or when they are at least 1/2^leaf_shift of the traversing lanes */
     uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
     uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;

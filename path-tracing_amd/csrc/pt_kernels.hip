@@ -312,8 +312,9 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
 /*
  * One step of a whole wave.
  * Lanes with `traversing` set hold a valid T.cur.  Lanes at an inner node always advance; lanes
- * at a leaf advance only when at least P.leaf_min lanes of the wave are at a leaf or no lane has
- * inner work, otherwise they wait one step with their state untouched.  Waiting changes nothing a
+ * at a leaf advance only when at least P.leaf_min lanes of the wave are at a leaf, or they are at
+ * least 1/2^P.leaf_shift of the traversing lanes, or no lane has inner work; otherwise they wait
+ * one step with their state untouched.  Waiting changes nothing a
  * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
@@ -324,7 +325,8 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
     const bool is_inner = traversing && !is_leaf;
     const unsigned long long inner_mask = __ballot(is_inner);
     const unsigned long long leaf_mask = __ballot(is_leaf);
-    const bool run_leaves = !inner_mask || (uint32_t)__popcll(leaf_mask) >= P.leaf_min;
+    const uint32_t n_leaf = (uint32_t)__popcll(leaf_mask), n_inner = (uint32_t)__popcll(inner_mask);
+    const bool run_leaves = !inner_mask || n_leaf >= P.leaf_min || (n_leaf << P.leaf_shift) >= n_leaf + n_inner;
     bool done = false;
     if (COUNT && ws) {
         ws->steps++;
@@ -572,8 +574,15 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_PHASE_DEAD 4      /* queue drained and path finished */
 #define PT_REFILL_MIN 16
 
+/* Five waves per SIMD: the register allocator then fits the kernel in 82 VGPRs (no scratch) where it
+ * takes 102 when left alone, and the fifth wave hides more of the record-load latency (measured
+ * +4.5 %); at six waves it has to spill and the gain is gone. */
+#ifndef PT_PATH_WAVES_PER_EU
+#define PT_PATH_WAVES_PER_EU 5
+#endif
+#define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
 template <bool EXACT, bool COUNT>
-__global__ __launch_bounds__(PT_BLOCK) void path_kernel(PTKernelParams P, uint32_t lds_entries) {
+__global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t gid = blockIdx.x * PT_BLOCK + threadIdx.x;
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */

@@ -168,9 +168,14 @@ __device__ __forceinline__ bool ray_div_safe(V3 o, V3 d) {
            pt_div_tame_coordinate(o.x) && pt_div_tame_coordinate(o.y) && pt_div_tame_coordinate(o.z);
 }
 
+/* All three quads of a triangle record are requested before the facing test: left alone the compiler
+ * fetches the normal, waits, and only then fetches the rest - two memory round trips per triangle. */
+#define PT_KEEP_LOADS_TOGETHER(a, b, c) asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x))
+
 /* ---- ray_triangle distance part, shader.wgsl:258-280 (edges and normal precomputed) ---- */
 __device__ __forceinline__ bool ray_triangle(V3 o, V3 d, const PTTriRecord *t, float &dst_out) {
     float4 q0 = t->q[0], q1 = t->q[1], q2 = t->q[2];
+    PT_KEEP_LOADS_TOGETHER(q0, q1, q2);
     V3 a = mk(q0.x, q0.y, q0.z), edge_ab = mk(q0.w, q1.x, q1.y), edge_ac = mk(q1.z, q1.w, q2.x);
     V3 normal_vector = mk(q2.y, q2.z, q2.w);
     float determinant = -dot3(d, normal_vector);
@@ -254,29 +259,32 @@ __device__ __forceinline__ void trav_begin(const PTKernelParams &P, Trav &T) {
 extern __shared__ uint32_t pt_lds[];
 
 struct WaveMem {
-    uint32_t *stk;          /* this lane's stack column in LDS */
-    uint32_t lds_entries;   /* stack entries kept in LDS; deeper ones go to `spill` */
-    uint32_t *spill;        /* this lane's overflow column in global memory (may be null when unused) */
+    uint32_t stk;           /* dword index of this lane's stack column in pt_lds */
+    uint32_t lds_entries;   /* stack entries kept in LDS; deeper ones go to `spill` (SPILL variants only) */
+    uint32_t *spill;        /* this lane's overflow column in global memory */
     uint32_t spill_stride;
 };
 
+/* SPILL = false: the whole stack is in LDS (plain ds_write / ds_read, no address-space choice). */
+template <bool SPILL>
 __device__ __forceinline__ void stack_push(const WaveMem &M, Trav &T, uint32_t v) {
-    if ((uint32_t)T.sp < M.lds_entries) M.stk[T.sp * 64] = v;
+    if (!SPILL || (uint32_t)T.sp < M.lds_entries) pt_lds[M.stk + (uint32_t)T.sp * 64u] = v;
     else M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride] = v;
     T.sp++;
 }
 
 /* after a visit: continue with the near child if one was kept, else pop; true = stack empty */
+template <bool SPILL>
 __device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
     if (T.cur != PT_REF_NONE) return false;
     if (T.sp == 0) return true;
     T.sp--;
-    if ((uint32_t)T.sp < M.lds_entries) T.cur = M.stk[T.sp * 64];
+    if (!SPILL || (uint32_t)T.sp < M.lds_entries) T.cur = pt_lds[M.stk + (uint32_t)T.sp * 64u];
     else T.cur = M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride];
     return false;
 }
 
-template <bool FAST, bool COUNT>
+template <bool FAST, bool COUNT, bool SPILL>
 __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, uint32_t lane, Trav &T, Counters &cn) {
     const PTInnerRecord *rec = P.inner + T.cur;
     float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
@@ -288,7 +296,7 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
     uint32_t ref_near, ref_far;
     if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
     else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
-    if (dst_far < T.best_t) stack_push(M, T, ref_far);
+    if (dst_far < T.best_t) stack_push<SPILL>(M, T, ref_far);
     T.cur = (dst_near < T.best_t) ? ref_near : PT_REF_NONE;
 }
 
@@ -318,7 +326,7 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
  * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
-template <bool FAST, bool COUNT>
+template <bool FAST, bool COUNT, bool SPILL>
 __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, uint32_t lane, bool traversing,
                                                Trav &T, Counters &cn, WaveStats *ws = nullptr) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
@@ -334,13 +342,13 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
         if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
     if (is_inner) {
-        inner_visit<FAST, COUNT>(P, M, lane, T, cn);
-        done = trav_advance(M, T);
+        inner_visit<FAST, COUNT, SPILL>(P, M, lane, T, cn);
+        done = trav_advance<SPILL>(M, T);
     }
     if (run_leaves) {
         if (is_leaf) {
             leaf_visit<COUNT>(P, T, cn);
-            done = trav_advance(M, T);
+            done = trav_advance<SPILL>(M, T);
         }
     }
     return done;
@@ -373,8 +381,8 @@ __device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveM
     trav_begin(P, T);
     bool traversing = active;
     while (__ballot(traversing)) {
-        bool done = fast ? trav_wave_step<true, COUNT>(P, M, lane, traversing, T, cn)
-                         : trav_wave_step<false, COUNT>(P, M, lane, traversing, T, cn);
+        bool done = fast ? trav_wave_step<true, COUNT, false>(P, M, lane, traversing, T, cn)
+                         : trav_wave_step<false, COUNT, false>(P, M, lane, traversing, T, cn);
         if (done) traversing = false;
     }
     if (active) {
@@ -504,7 +512,7 @@ template <bool EXACT, bool COUNT, bool AOV>
 __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
-    M.stk = pt_lds + wave * P.stack_entries * 64u + lane;
+    M.stk = wave * P.stack_entries * 64u + lane;
     M.lds_entries = P.stack_entries; M.spill = nullptr; M.spill_stride = 0;
     /* block = 16x16 pixels, wave = 8x8 tile */
     const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
@@ -581,12 +589,12 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_PATH_WAVES_PER_EU 5
 #endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
-template <bool EXACT, bool COUNT>
+template <bool EXACT, bool COUNT, bool SPILL>
 __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t gid = blockIdx.x * PT_BLOCK + threadIdx.x;
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
-    M.stk = pt_lds + wave * lds_entries * 64u + lane;
+    M.stk = wave * lds_entries * 64u + lane;
     M.lds_entries = lds_entries; M.spill = P.spill + gid; M.spill_stride = P.spill_stride;
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
@@ -710,8 +718,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
             unsigned long long waiting = __ballot(phase == PT_PHASE_HIT);
             if ((uint32_t)__popcll(waiting) >= P.refill_min) break;
             const bool traversing = phase == PT_PHASE_TRAV;
-            bool done = fast ? trav_wave_step<true, COUNT>(P, M, lane, traversing, T, cn, &ws)
-                             : trav_wave_step<false, COUNT>(P, M, lane, traversing, T, cn, &ws);
+            bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, lane, traversing, T, cn, &ws)
+                             : trav_wave_step<false, COUNT, SPILL>(P, M, lane, traversing, T, cn, &ws);
             if (done) phase = PT_PHASE_HIT;
         }
         if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
@@ -780,7 +788,8 @@ int pt_max_stack_entries(void) { return 64; }       /* 64 entries x 4 waves x 25
 /* the persistent grid never exceeds 8 blocks per CU */
 uint32_t pt_lane_stride(int num_cus) { return (uint32_t)num_cus * 8u * PT_BLOCK; }
 
-#define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS */
+#define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS when it spills */
+#define PT_PATH_LDS_ALL 30        /* deepest tree whose whole stack the path kernel keeps in LDS */
 
 static size_t block_lds_bytes(uint32_t entries) {
     return (size_t)PT_WAVES_PER_BLOCK * (size_t)entries * 64 * sizeof(uint32_t);
@@ -788,7 +797,7 @@ static size_t block_lds_bytes(uint32_t entries) {
 
 /* stack entries per lane the path kernel spills to global memory, for sizing PTKernelParams::spill */
 uint32_t pt_spill_entries(uint32_t stack_entries) {
-    return stack_entries > PT_PATH_LDS_STACK ? stack_entries - PT_PATH_LDS_STACK : 0;
+    return stack_entries > PT_PATH_LDS_STACK ? stack_entries - PT_PATH_LDS_STACK : 0;     /* PT_FORCE_SPILL may ask for it */
 }
 
 hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
@@ -807,24 +816,35 @@ hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, b
     return hipGetLastError();
 }
 
+template <bool SPILL>
+static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool count, dim3 grid, size_t lds, uint32_t lds_entries,
+                                 hipStream_t st) {
+    dim3 block(PT_BLOCK);
+    if (count) {
+        if (exact) hipLaunchKernelGGL((path_kernel<true, true, SPILL>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, true, SPILL>), grid, block, lds, st, kp, lds_entries);
+    } else {
+        if (exact) hipLaunchKernelGGL((path_kernel<true, false, SPILL>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, false, SPILL>), grid, block, lds, st, kp, lds_entries);
+    }
+}
+
 hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
     if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
-    /* persistent grid: as many 4-wave blocks per CU as stay resident (8 at most) */
-    uint32_t lds_entries = kp.stack_entries < PT_PATH_LDS_STACK ? kp.stack_entries : PT_PATH_LDS_STACK;
-    if (const char *e = getenv("PT_LDS_STACK")) { int v = atoi(e); if (v >= 1 && (uint32_t)v <= kp.stack_entries && v >= PT_PATH_LDS_STACK) lds_entries = (uint32_t)v; }
+    /* Trees of up to PT_PATH_LDS_ALL levels keep the whole stack in LDS (5 resident blocks x 30 KiB fit
+     * the CU's 160 KiB); deeper ones keep PT_PATH_LDS_STACK entries there and the rest in global memory. */
+    bool spill = kp.stack_entries > PT_PATH_LDS_ALL;
+    if (getenv("PT_FORCE_SPILL") && kp.stack_entries > PT_PATH_LDS_STACK) spill = true;
+    uint32_t lds_entries = spill ? PT_PATH_LDS_STACK : kp.stack_entries;
     const size_t lds = block_lds_bytes(lds_entries);
+    /* persistent grid: as many 4-wave blocks per CU as stay resident (8 at most) */
     int per_cu = (int)((160 * 1024 - 512) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
-    dim3 grid(num_cus * per_cu), block(PT_BLOCK);
-    if (count) {
-        if (exact) hipLaunchKernelGGL((path_kernel<true, true>), grid, block, lds, st, kp, lds_entries);
-        else       hipLaunchKernelGGL((path_kernel<false, true>), grid, block, lds, st, kp, lds_entries);
-    } else {
-        if (exact) hipLaunchKernelGGL((path_kernel<true, false>), grid, block, lds, st, kp, lds_entries);
-        else       hipLaunchKernelGGL((path_kernel<false, false>), grid, block, lds, st, kp, lds_entries);
-    }
+    dim3 grid(num_cus * per_cu);
+    if (spill) launch_paths_variant<true>(kp, exact, count, grid, lds, lds_entries, st);
+    else       launch_paths_variant<false>(kp, exact, count, grid, lds, lds_entries, st);
     return hipGetLastError();
 }
 

@@ -30,6 +30,10 @@ int orc_uses_shared_math(void) { return 0; }
 #define ORC_FAR 1000000.0f         /* shader.wgsl:142,177 */
 #define ORC_BOX_MISS 999999999.0f  /* shader.wgsl:254 */
 #define ORC_MAX_STACK 4096
+/* lets an analysis tool that includes this file watch the node visits of a traversal */
+#ifndef ORC_VISIT_HOOK
+#define ORC_VISIT_HOOK(is_leaf) ((void)0)
+#endif
 
 /* ---- vector helpers with the evaluation order fixed in pt_oracle.h ---- */
 static inline orc_v3 v3(float x, float y, float z) { orc_v3 r = {x, y, z}; return r; }
@@ -253,6 +257,7 @@ void orc_ray_triangle_bvh(const orc_params *p, const orc_scene *s, const float o
         int32_t node_index = node_stack[stack_index];
         const float *node = s->bvh + 9 * (size_t)node_index;   /* get_node, :165-167 */
         popped++;
+        ORC_VISIT_HOOK(node[8] == 0.0f);
         if (node[8] == 0.0f) {
             uint32_t first = (uint32_t)node[6];
             uint32_t end = (uint32_t)(node[6] + node[7]);

@@ -55,7 +55,7 @@ struct pt_ctx {
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
     bool fast_div = false;
-    uint32_t refill_min = 58;
+    uint32_t refill_min = 60;
     uint32_t leaf_min = 8;
     uint32_t leaf_shift = 2;
 

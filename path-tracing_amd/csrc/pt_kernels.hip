@@ -219,7 +219,7 @@ __device__ __forceinline__ bool ray_sphere(V3 o, V3 d, const float *s, float &ds
 
 struct Trav {
     uint32_t cur;      /* node to visit next, or PT_REF_NONE: pop one */
-    int sp;            /* entries on the LDS stack */
+    uint32_t sp;       /* stack pointer, see stack_push */
     float best_t;
     int32_t best_id;
     RayPk R;           /* origin, direction and 1/direction in the layout ray_box2 wants */
@@ -236,9 +236,9 @@ __device__ __forceinline__ V3 ray_origin(const RayPk &R) { return mk(R.oxy.x, R.
 __device__ __forceinline__ V3 ray_dir(const RayPk &R) { return mk(R.dxy.x, R.dxy.y, R.dzz.x); }
 
 /* T.R must hold the ray */
-__device__ __forceinline__ void trav_begin(const PTKernelParams &P, Trav &T) {
+__device__ __forceinline__ void trav_begin(const PTKernelParams &P, uint32_t stack_bottom_offset, Trav &T) {
     T.cur = P.root_ref;
-    T.sp = 0;
+    T.sp = stack_bottom_offset;
     T.best_t = PT_FAR;
     T.best_id = PT_NONE;
 }
@@ -257,39 +257,66 @@ __device__ __forceinline__ void trav_begin(const PTKernelParams &P, Trav &T) {
  * ALU, the vector-memory pipeline and the L1 each about half busy.
  */
 extern __shared__ uint32_t pt_lds[];
+__device__ __forceinline__ uint32_t lane_id();
 
 struct WaveMem {
-    uint32_t stk;           /* dword index of this lane's stack column in pt_lds */
-    uint32_t lds_entries;   /* stack entries kept in LDS; deeper ones go to `spill` (SPILL variants only) */
-    uint32_t *spill;        /* this lane's overflow column in global memory */
+    uint32_t base;          /* byte offset in pt_lds of this wave's stack rows (wave-uniform) */
+    uint32_t limit;         /* base + 256 * entries kept in LDS (wave-uniform); deeper entries go to `spill` */
+    uint32_t *spill;        /* this lane's overflow column in global memory (SPILL variants only) */
     uint32_t spill_stride;
 };
+
+/* The stack pointer T.sp is the LDS byte offset of the next free entry of this lane's column:
+ * base + 4 * lane + 256 * depth.  Empty <=> T.sp < base + 256, a compare against a scalar. */
+__device__ __forceinline__ uint32_t stack_bottom(const WaveMem &M) { return M.base + 4u * lane_id(); }
+__device__ __forceinline__ bool stack_empty(const WaveMem &M, const Trav &T) { return T.sp < M.base + 256u; }
+__device__ __forceinline__ uint32_t *lds_word(uint32_t byte_offset) {
+    return (uint32_t *)((char *)pt_lds + byte_offset);
+}
 
 /* SPILL = false: the whole stack is in LDS (plain ds_write / ds_read, no address-space choice). */
 template <bool SPILL>
 __device__ __forceinline__ void stack_push(const WaveMem &M, Trav &T, uint32_t v) {
-    if (!SPILL || (uint32_t)T.sp < M.lds_entries) pt_lds[M.stk + (uint32_t)T.sp * 64u] = v;
-    else M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride] = v;
-    T.sp++;
+    if (!SPILL || T.sp < M.limit) *lds_word(T.sp) = v;
+    else M.spill[((T.sp - M.limit) >> 8) * M.spill_stride] = v;
+    T.sp += 256u;
 }
 
 /* after a visit: continue with the near child if one was kept, else pop; true = stack empty */
 template <bool SPILL>
 __device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
     if (T.cur != PT_REF_NONE) return false;
-    if (T.sp == 0) return true;
-    T.sp--;
-    if (!SPILL || (uint32_t)T.sp < M.lds_entries) T.cur = pt_lds[M.stk + (uint32_t)T.sp * 64u];
-    else T.cur = M.spill[((uint32_t)T.sp - M.lds_entries) * M.spill_stride];
+    if (stack_empty(M, T)) return true;
+    T.sp -= 256u;
+    if (!SPILL || T.sp < M.limit) T.cur = *lds_word(T.sp);
+    else T.cur = M.spill[((T.sp - M.limit) >> 8) * M.spill_stride];
     return false;
 }
 
 template <bool FAST, bool COUNT, bool SPILL>
-__device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, uint32_t lane, Trav &T, Counters &cn) {
+__device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, Trav &T, Counters &cn) {
     const PTInnerRecord *rec = P.inner + T.cur;
     float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
     float dst_a, dst_b;
     ray_box2<FAST>(T.R, q0, q1, q2, dst_a, dst_b);
+#ifdef PT_ABL_DIV2      /* sensitivity probe: a second box test whose result cannot change anything */
+    {
+        float xa, xb;
+        float4 p0 = q0, p1 = q1, p2 = q2;
+        asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x));
+        ray_box2<FAST>(T.R, p0, p1, p2, xa, xb);
+        dst_a = fmin_(dst_a, fabsf(xa) + 3.0e38f);
+        dst_b = fmin_(dst_b, fabsf(xb) + 3.0e38f);
+    }
+#endif
+#ifdef PT_ABL_LOAD2     /* sensitivity probe: four more 16-byte loads, PT_ABL_LOAD2 records back */
+    {
+        const PTInnerRecord *r2 = P.inner + (T.cur >= PT_ABL_LOAD2 ? T.cur - PT_ABL_LOAD2 : T.cur);
+        float4 e0 = r2->q[0], e1 = r2->q[1], e2 = r2->q[2], e3 = r2->q[3];
+        float s = e0.x + e1.x + e2.x + e3.x;
+        dst_a = fmin_(dst_a, fabsf(s) + 3.0e38f);
+    }
+#endif
     if (COUNT) cn.boxes += 2;
     uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
     float dst_near, dst_far;
@@ -327,7 +354,7 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
 template <bool FAST, bool COUNT, bool SPILL>
-__device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, uint32_t lane, bool traversing,
+__device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, bool traversing,
                                                Trav &T, Counters &cn, WaveStats *ws = nullptr) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
     const bool is_inner = traversing && !is_leaf;
@@ -342,7 +369,7 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
         if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
     if (is_inner) {
-        inner_visit<FAST, COUNT, SPILL>(P, M, lane, T, cn);
+        inner_visit<FAST, COUNT, SPILL>(P, M, T, cn);
         done = trav_advance<SPILL>(M, T);
     }
     if (run_leaves) {
@@ -368,7 +395,7 @@ __device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V
  * index order, then the BVH (which does not see the sphere distance), strict `<`
  * everywhere.  `active` lanes take part; the division form is chosen per wave. */
 template <bool COUNT>
-__device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveMem &M, uint32_t lane, bool active, V3 o, V3 d,
+__device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveMem &M, bool active, V3 o, V3 d,
                                             float &t_out, int32_t &id_out, Counters &cn) {
     float best = PT_FAR;
     int32_t id = PT_NONE;
@@ -378,11 +405,11 @@ __device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveM
     }
     Trav T;
     raypk_set(T.R, o, d);
-    trav_begin(P, T);
+    trav_begin(P, stack_bottom(M), T);
     bool traversing = active;
     while (__ballot(traversing)) {
-        bool done = fast ? trav_wave_step<true, COUNT, false>(P, M, lane, traversing, T, cn)
-                         : trav_wave_step<false, COUNT, false>(P, M, lane, traversing, T, cn);
+        bool done = fast ? trav_wave_step<true, COUNT, false>(P, M, traversing, T, cn)
+                         : trav_wave_step<false, COUNT, false>(P, M, traversing, T, cn);
         if (done) traversing = false;
     }
     if (active) {
@@ -512,8 +539,8 @@ template <bool EXACT, bool COUNT, bool AOV>
 __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
-    M.stk = wave * P.stack_entries * 64u + lane;
-    M.lds_entries = P.stack_entries; M.spill = nullptr; M.spill_stride = 0;
+    M.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) * P.stack_entries * 256u;
+    M.limit = M.base + P.stack_entries * 256u; M.spill = nullptr; M.spill_stride = 0;
     /* block = 16x16 pixels, wave = 8x8 tile */
     const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
@@ -525,7 +552,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     float t = PT_FAR;
     int32_t id = PT_NONE;
     if (valid) primary_ray(P, px, py, rd, pixel_index);
-    closest_hit<COUNT>(P, M, lane, valid, ro, rd, t, id, cn);
+    closest_hit<COUNT>(P, M, valid, ro, rd, t, id, cn);
     const uint32_t pixel = py * P.width + px;
     if (AOV) {
         if (valid) { P.out_ids[pixel] = id; P.out_dist[pixel] = t; }
@@ -568,34 +595,29 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 
 /* ======================= bounces ======================= */
 /*
- * Lane phases of the persistent path kernel.  A lane owns one path at a time; the
+ * The persistent path kernel.  A lane owns one path at a time; the
  * BVH traversal of its current ray is resumable (Trav), so a wave does not have
- * to wait for its slowest lane: as soon as PT_REFILL_MIN lanes have finished
+ * to wait for its slowest lane: as soon as P.refill_min lanes have finished
  * their traversal the wave leaves the traversal loop, shades those lanes (which
  * either produces their next ray or ends the path and pulls a new one from the
  * global queue) and re-enters the loop with the other lanes' traversals intact.
  */
-#define PT_PHASE_IDLE 0      /* no path: wants one from the queue */
-#define PT_PHASE_RAY 1       /* has a ray that has not started its cast */
-#define PT_PHASE_TRAV 2      /* BVH traversal in progress */
-#define PT_PHASE_HIT 3       /* cast complete, waiting to be shaded */
-#define PT_PHASE_DEAD 4      /* queue drained and path finished */
-#define PT_REFILL_MIN 16
-
-/* Five waves per SIMD: the register allocator then fits the kernel in 82 VGPRs (no scratch) where it
- * takes 102 when left alone, and the fifth wave hides more of the record-load latency (measured
- * +4.5 %); at six waves it has to spill and the gain is gone. */
+/* Six waves per SIMD: told so, the register allocator fits the kernel in 79 VGPRs without scratch
+ * (left alone it takes 102 and runs at four).  Measured: 4 waves 3.68 ms per frame, 5 waves 3.51,
+ * 6 waves 3.10 (with the other changes made since).  The whole-stack-in-LDS variant reaches six
+ * resident blocks per CU for trees of up to 26 levels (6 x 26 KiB), five up to 30. */
 #ifndef PT_PATH_WAVES_PER_EU
-#define PT_PATH_WAVES_PER_EU 5
+#define PT_PATH_WAVES_PER_EU 6
 #endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
 template <bool EXACT, bool COUNT, bool SPILL>
 __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t gid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
-    M.stk = wave * lds_entries * 64u + lane;
-    M.lds_entries = lds_entries; M.spill = P.spill + gid; M.spill_stride = P.spill_stride;
+    M.base = wave * lds_entries * 256u;
+    M.limit = M.base + lds_entries * 256u;
+    M.spill = SPILL ? P.spill + (blockIdx.x * PT_BLOCK + threadIdx.x) : nullptr;
+    M.spill_stride = P.spill_stride;
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
     const uint32_t total = P.ctrl->hit_count * per_hit;
@@ -605,7 +627,12 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
     uint32_t queues_done = 0;
     Counters cn = {0, 0, 0, 0};
 
-    int phase = PT_PHASE_IDLE;
+    /* the lane's phase, one flag each (the compiler keeps them as lane masks in scalar registers) */
+    bool idle = true;        /* no path: wants one from the queue */
+    bool has_ray = false;    /* has a ray that has not started its cast */
+    bool trav = false;       /* BVH traversal in progress */
+    bool hit = false;        /* cast complete, waiting to be shaded */
+    bool dead = false;       /* queue drained and path finished */
     bool drained = total == 0;
     uint32_t slot = 0, seed = 0, i = 0;
     V3 light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
@@ -620,9 +647,9 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
     if (COUNT) t_start = __builtin_amdgcn_s_memtime();
 
     for (;;) {
-        if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(phase == PT_PHASE_HIT)); }
+        if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(hit)); }
         /* (A) shade the lanes whose cast is complete: one iteration of trace, shader.wgsl:118-133 */
-        if (phase == PT_PHASE_HIT) {
+        if (hit) {
             float t = sph_t;
             int32_t id = sph_id;
             V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
@@ -637,28 +664,29 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                 if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
                 finished = true;
             }
+            hit = false;
             if (finished) {
                 P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
-                phase = PT_PHASE_IDLE;
+                idle = true;
             } else {
                 raypk_set(T.R, ro, rd);
-                phase = PT_PHASE_RAY;
+                has_ray = true;
             }
         }
         /* (B) idle lanes pull new paths: one atomic per wave.  The queue is cut into 8 equal,
          * contiguous parts, one per XCD (consecutive paths belong to neighbouring pixels, so a
          * part is a compact piece of the image and the BVH nodes its rays visit stay in that
          * XCD's 4 MiB L2).  A wave drains its own XCD's part first, then helps the others. */
-        unsigned long long need = __ballot(phase == PT_PHASE_IDLE);
+        unsigned long long need = __ballot(idle);
         if (need) {
             while (!drained) {
                 const uint32_t q_start = queue * part < total ? queue * part : total;
                 const uint32_t q_len = (total - q_start < part) ? total - q_start : part;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
+                if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
                 base = __shfl(base, 0, 64);
                 const bool exhausted = base + (uint32_t)__popcll(need) >= q_len;
-                if (base < q_len && phase == PT_PHASE_IDLE) {
+                if (base < q_len && idle) {
                     const uint32_t local = base + prefix_count(need);
                     if (local < q_len) {
                         const uint32_t item = q_start + local;
@@ -686,7 +714,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                             P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
                         } else {
                             raypk_set(T.R, ro, rd);
-                            phase = PT_PHASE_RAY;
+                            idle = false;
+                            has_ray = true;
                         }
                     }
                 }
@@ -696,38 +725,36 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                 }
                 if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
             }
-            if (drained && phase == PT_PHASE_IDLE) phase = PT_PHASE_DEAD;
+            if (drained && idle) { idle = false; dead = true; }
         }
         /* (C) new rays: spheres first (shader.wgsl:144-154), then set up the traversal */
-        if (phase == PT_PHASE_RAY) {
+        if (has_ray) {
             V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
             spheres_closest(P, ro, rd, sph_t, sph_id);
-            trav_begin(P, T);
+            trav_begin(P, stack_bottom(M), T);
             safe = ray_div_safe(ro, rd);
             if (COUNT) cn.casts++;
-            phase = PT_PHASE_TRAV;
+            has_ray = false;
+            trav = true;
         }
-        if (!__ballot(phase != PT_PHASE_DEAD)) break;
+        if (!__ballot(!dead)) break;
         /* (D) traverse until enough lanes wait for shading (or, at the tail, all are done) */
-        const bool fast = P.fast_div && __all(phase != PT_PHASE_TRAV || safe);
+        const bool fast = P.fast_div && __all(!trav || safe);
         unsigned long long t0 = 0;
         if (COUNT) t0 = __builtin_amdgcn_s_memtime();
         for (;;) {
-            unsigned long long trav = __ballot(phase == PT_PHASE_TRAV);
-            if (!trav) break;
-            unsigned long long waiting = __ballot(phase == PT_PHASE_HIT);
-            if ((uint32_t)__popcll(waiting) >= P.refill_min) break;
-            const bool traversing = phase == PT_PHASE_TRAV;
-            bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, lane, traversing, T, cn, &ws)
-                             : trav_wave_step<false, COUNT, SPILL>(P, M, lane, traversing, T, cn, &ws);
-            if (done) phase = PT_PHASE_HIT;
+            if (!__ballot(trav)) break;
+            if ((uint32_t)__popcll(__ballot(hit)) >= P.refill_min) break;
+            bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, trav, T, cn, &ws)
+                             : trav_wave_step<false, COUNT, SPILL>(P, M, trav, T, cn, &ws);
+            if (done) { trav = false; hit = true; }
         }
         if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
     }
     if (COUNT) {
         flush_counters(P, cn, 1ull, true);
         /* diagnostics: where a wave's time and lanes go (pt_get_debug_stats) */
-        if (lane == 0) {
+        if (lane_id() == 0) {
             atomicAdd(&P.counters[8], __builtin_amdgcn_s_memtime() - t_start);
             atomicAdd(&P.counters[9], t_trav);
             atomicAdd(&P.counters[10], ws.steps);

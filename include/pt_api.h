@@ -223,6 +223,20 @@ int pt_stl_format_file(const char *stl_path, const char *bin_path, double scale,
 /* Message of the calling thread's last failed pt_stl_format* call. */
 const char *pt_stl_format_error(void);
 
+/*
+ * Camera motion of the reference host (pure host code), replaces State::update_camera
+ * (src/main.rs:45-115) and its rotate_vector (src/main.rs:117-142).
+ * keys = [W, S, D, A, Space, ShiftLeft, I, K, L, J, O, U] (main.rs:39, 710-721), non-zero =
+ * pressed.  One call = one tick: the pressed keys move the camera by `speed` along and turn it by
+ * `rot_speed` degrees about its local axes (CAMERA_SPEED = CAMERA_ROT_SPEED = 1.0, main.rs:17-18),
+ * position and rotation_degrees are updated in place.  *any_key (may be NULL) receives 1 when a
+ * key is pressed: the caller must then restart the accumulation with frame_count = 0
+ * (main.rs:47-49) and pass the new pose to pt_set_camera.
+ */
+int pt_update_camera(const uint8_t keys[12], float speed, float rot_speed,
+                     float position[3], float rotation_degrees[3], int *any_key);
+int pt_host_rotate_vector(const float v[3], const float rotation_degrees[3], float out[3]);
+
 #ifdef __cplusplus
 }
 #endif

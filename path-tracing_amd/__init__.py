@@ -64,7 +64,13 @@ API_SYMBOLS = [
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
+    "pt_update_camera", "pt_host_rotate_vector",
 ]
+
+# key order of State::keys_pressed (main.rs:39)
+KEYS = ("W", "S", "D", "A", "Space", "Shift", "I", "K", "L", "J", "O", "U")
+CAMERA_SPEED = 1.0        # main.rs:17
+CAMERA_ROT_SPEED = 1.0    # main.rs:18
 
 
 class PtError(RuntimeError):
@@ -127,6 +133,8 @@ def load_library():
     L.pt_stl_format_file.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.POINTER(C.c_uint64)]
     L.pt_stl_format_error.argtypes = []
     L.pt_stl_format_error.restype = C.c_char_p
+    L.pt_update_camera.argtypes = [C.POINTER(C.c_uint8), C.c_float, C.c_float, fp, fp, C.POINTER(C.c_int)]
+    L.pt_host_rotate_vector.argtypes = [fp, fp, fp]
     _lib = L
     return L
 
@@ -168,6 +176,38 @@ def bvh_build(triangles, max_depth):
     nodes = np.ctypeslib.as_array(nodes_p, shape=(n.value, 9)).copy()
     L.pt_free(nodes_p)
     return out_tr, nodes
+
+
+def _key_array(keys):
+    """keys: iterable of key names from KEYS (or a 12-element sequence of truth values)."""
+    keys = list(keys)
+    if len(keys) == 12 and not any(isinstance(k, str) for k in keys):
+        flags = [1 if k else 0 for k in keys]
+    else:
+        flags = [0] * 12
+        for k in keys:
+            flags[KEYS.index(k)] = 1
+    return (C.c_uint8 * 12)(*flags)
+
+
+def update_camera(keys, position, rotation_degrees, speed=CAMERA_SPEED, rot_speed=CAMERA_ROT_SPEED):
+    """One tick of State::update_camera (main.rs:45-115) on plain values.
+    Returns (position, rotation_degrees, any_key) with f32-exact list values."""
+    L = load_library()
+    pos, rot, any_key = _f3(position), _f3(rotation_degrees), C.c_int()
+    rc = L.pt_update_camera(_key_array(keys), float(speed), float(rot_speed), pos, rot, C.byref(any_key))
+    if rc:
+        raise PtError(rc, "pt_update_camera")
+    return [pos[0], pos[1], pos[2]], [rot[0], rot[1], rot[2]], bool(any_key.value)
+
+
+def host_rotate_vector(v, rotation_degrees):
+    """State::rotate_vector (main.rs:117-142)."""
+    out = (C.c_float * 3)()
+    rc = load_library().pt_host_rotate_vector(_f3(v), _f3(rotation_degrees), out)
+    if rc:
+        raise PtError(rc, "pt_host_rotate_vector")
+    return [out[0], out[1], out[2]]
 
 
 def stl_format(stl_text, scale=1.0):
@@ -261,6 +301,14 @@ class Renderer:
         self._check(self._L.pt_set_camera(self._ctx, _f3(position), _f3(rotation_degrees)))
         if reset:
             self.frame_count = 0          # main.rs:47-49
+
+    def update_camera(self, keys):
+        """One timer tick with `keys` held (main.rs:674 -> :45-115): moves the camera and, if any
+        key is held, restarts the accumulation.  Returns True when the pose changed."""
+        pos, rot, any_key = update_camera(keys, self.camera_position, self.camera_rotation)
+        if any_key:
+            self.set_camera(pos, rot, reset=True)
+        return any_key
 
     # -- frames ------------------------------------------------------------
     def render(self, n_frames=1):

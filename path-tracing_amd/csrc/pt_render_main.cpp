@@ -10,7 +10,13 @@
  *
  * usage: pt_render --tris a.bin --bvh a_bvh.bin [--sphere x,y,z,r,cr,cg,cb,er,eg,eb,es,sm]...
  *                  [--cam x,y,z] [--rot a,b,c] [--size WxH] [--rpp N] [--frames N]
- *                  [--bounces N] [--device D] [--exact] [--out image.ppm]
+ *                  [--bounces N] [--device D] [--exact] [--out image.ppm] [--walk SCRIPT]
+ *
+ * --walk plays the reference's timer loop (src/main.rs:674-676: update_camera, then render) for
+ * a scripted key sequence instead of --frames: SCRIPT is a comma-separated list of KEYS*TICKS,
+ * KEYS being letters of "WSDA^vIKLJOU" (^ = Space, v = ShiftLeft) held together, or "-" for no
+ * key.  Example: "W*10,WL*20,-*16" walks forward, walks while turning, then stands still for 16
+ * ticks, during which the image accumulates (a tick with a key held restarts it, main.rs:47-49).
  */
 #include "../../include/pt_api.h"
 
@@ -33,6 +39,32 @@ static bool parse_floats(const char *s, float *out, int n) {
     return *s == 0;
 }
 
+struct WalkStep { uint8_t keys[12]; unsigned ticks; };
+
+static bool parse_walk(const char *s, std::vector<WalkStep> &out) {
+    static const char codes[] = "WSDA^vIKLJOU";         /* order of State::keys_pressed, src/main.rs:39 */
+    while (*s) {
+        WalkStep st;
+        memset(&st, 0, sizeof(st));
+        bool any = false;
+        for (; *s && *s != '*'; s++, any = true) {
+            if (*s == '-') continue;
+            const char *c = strchr(codes, *s);
+            if (!c) return false;
+            st.keys[c - codes] = 1;
+        }
+        if (!any || *s != '*') return false;
+        char *end = nullptr;
+        long n = strtol(s + 1, &end, 10);
+        if (end == s + 1 || n < 0) return false;
+        st.ticks = (unsigned)n;
+        out.push_back(st);
+        s = end;
+        if (*s == ',') s++; else if (*s) return false;
+    }
+    return true;
+}
+
 static unsigned char to_srgb8(float v) {
     if (!(v > 0.0f)) v = 0.0f;           /* also maps NaN to 0 */
     if (v > 1.0f) v = 1.0f;
@@ -48,6 +80,7 @@ int main(int argc, char **argv) {
     pt_default_params(&p);
     unsigned frames = 1;
     int device = 0;
+    std::vector<WalkStep> walk;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto need = [&](const char *what) -> const char * {
@@ -66,6 +99,7 @@ int main(int argc, char **argv) {
         else if (a == "--bounces") p.max_bounce_count = (unsigned)atoi(need("--bounces"));
         else if (a == "--device") device = atoi(need("--device"));
         else if (a == "--exact") p.flags |= PT_FLAG_EXACT_MATH;
+        else if (a == "--walk") { if (!parse_walk(need("--walk"), walk)) { fprintf(stderr, "bad --walk\n"); return 2; } }
         else { fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
     if (tris.empty() || bvh.empty()) { fprintf(stderr, "--tris and --bvh are required\n"); return 2; }
@@ -77,9 +111,30 @@ int main(int argc, char **argv) {
     }
     pt_set_camera(ctx, cam, rot);
     auto t0 = std::chrono::steady_clock::now();
-    /* State::render once per frame, frame_count 0,1,2,... (src/main.rs:448-452,510) */
-    if (pt_render_frames(ctx, 0, frames) || pt_synchronize(ctx)) {
-        fprintf(stderr, "render: %s\n", pt_last_error(ctx)); pt_destroy(ctx); return 1;
+    if (walk.empty()) {
+        /* State::render once per frame, frame_count 0,1,2,... (src/main.rs:448-452,510) */
+        if (pt_render_frames(ctx, 0, frames) || pt_synchronize(ctx)) {
+            fprintf(stderr, "render: %s\n", pt_last_error(ctx)); pt_destroy(ctx); return 1;
+        }
+    } else {
+        /* the timer loop: update_camera, then render (src/main.rs:674-676) */
+        uint32_t frame_count = 0;
+        frames = 0;
+        for (const WalkStep &st : walk) {
+            for (unsigned t = 0; t < st.ticks; t++) {
+                int any_key = 0;
+                pt_update_camera(st.keys, 1.0f, 1.0f, cam, rot, &any_key);     /* CAMERA_SPEED, CAMERA_ROT_SPEED */
+                if (any_key) { frame_count = 0; pt_set_camera(ctx, cam, rot); }
+                if (pt_render_frames(ctx, frame_count, 1)) {
+                    fprintf(stderr, "render: %s\n", pt_last_error(ctx)); pt_destroy(ctx); return 1;
+                }
+                frame_count++;
+                frames++;
+            }
+        }
+        if (pt_synchronize(ctx)) { fprintf(stderr, "render: %s\n", pt_last_error(ctx)); pt_destroy(ctx); return 1; }
+        printf("camera after the walk: position %.9g,%.9g,%.9g rotation %.9g,%.9g,%.9g, %u accumulated frame(s)\n",
+               cam[0], cam[1], cam[2], rot[0], rot[1], rot[2], frame_count);
     }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::vector<float> img((size_t)p.width * p.height * 3);

@@ -347,21 +347,24 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
 /*
  * One step of a whole wave.
  * Lanes with `traversing` set hold a valid T.cur.  Lanes at an inner node always advance; lanes
- * at a leaf advance only when at least P.leaf_min lanes of the wave are at a leaf, or they are at
- * least 1/2^P.leaf_shift of the traversing lanes, or no lane has inner work; otherwise they wait
- * one step with their state untouched.  Waiting changes nothing a
+ * at a leaf advance only in some steps and otherwise wait with their state untouched.  With
+ * leaf_turn < 0 they advance when at least P.leaf_min lanes of the wave are at a leaf, or they are
+ * at least 1/2^P.leaf_shift of the traversing lanes, or no lane has inner work; with leaf_turn >= 0
+ * the caller decides (1 = this step takes the leaves).  Waiting changes nothing a
  * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
 template <bool FAST, bool COUNT, bool SPILL>
 __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, bool traversing,
-                                               Trav &T, Counters &cn, WaveStats *ws = nullptr) {
+                                               Trav &T, Counters &cn, WaveStats *ws = nullptr, int leaf_turn = -1) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
     const bool is_inner = traversing && !is_leaf;
     const unsigned long long inner_mask = __ballot(is_inner);
     const unsigned long long leaf_mask = __ballot(is_leaf);
     const uint32_t n_leaf = (uint32_t)__popcll(leaf_mask), n_inner = (uint32_t)__popcll(inner_mask);
-    const bool run_leaves = !inner_mask || n_leaf >= P.leaf_min || (n_leaf << P.leaf_shift) >= n_leaf + n_inner;
+    bool run_leaves;
+    if (leaf_turn < 0) run_leaves = !inner_mask || n_leaf >= P.leaf_min || (n_leaf << P.leaf_shift) >= n_leaf + n_inner;
+    else run_leaves = leaf_turn > 0 && leaf_mask;       /* the path kernel gives leaves fixed turns */
     bool done = false;
     if (COUNT && ws) {
         ws->steps++;
@@ -609,6 +612,12 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #ifndef PT_PATH_WAVES_PER_EU
 #define PT_PATH_WAVES_PER_EU 6
 #endif
+#ifndef PT_STEPS_PER_CHECK
+#define PT_STEPS_PER_CHECK 6
+#endif
+#ifndef PT_LEAF_PERIOD
+#define PT_LEAF_PERIOD 3
+#endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
 template <bool EXACT, bool COUNT, bool SPILL>
 __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
@@ -745,9 +754,16 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
         for (;;) {
             if (!__ballot(trav)) break;
             if ((uint32_t)__popcll(__ballot(hit)) >= P.refill_min) break;
-            bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, trav, T, cn, &ws)
-                             : trav_wave_step<false, COUNT, SPILL>(P, M, trav, T, cn, &ws);
-            if (done) { trav = false; hit = true; }
+#pragma unroll
+            /* Several steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
+             * step also runs the triangle code for the lanes that stand at a leaf (they wait for it): measured
+             * faster than deciding from lane counts in every step (2.98 -> 2.90 ms per frame). */
+            for (int rep = 0; rep < PT_STEPS_PER_CHECK; rep++) {
+                const int turn = (rep % PT_LEAF_PERIOD) == PT_LEAF_PERIOD - 1 ? 1 : 0;
+                bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, trav, T, cn, &ws, turn)
+                                 : trav_wave_step<false, COUNT, SPILL>(P, M, trav, T, cn, &ws, turn);
+                if (done) { trav = false; hit = true; }
+            }
         }
         if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
     }

@@ -232,6 +232,12 @@ __device__ __forceinline__ void raypk_set(RayPk &R, V3 o, V3 d) {
     R.yxy = mk2(1.0f / d.x, 1.0f / d.y); R.yzz = mk2(iz, iz);
 }
 
+/* origin and direction only (a ray that is shaded, not cast) */
+__device__ __forceinline__ void raypk_set_od(RayPk &R, V3 o, V3 d) {
+    R.oxy = mk2(o.x, o.y); R.ozz = mk2(o.z, o.z);
+    R.dxy = mk2(d.x, d.y); R.dzz = mk2(d.z, d.z);
+}
+
 __device__ __forceinline__ V3 ray_origin(const RayPk &R) { return mk(R.oxy.x, R.oxy.y, R.ozz.x); }
 __device__ __forceinline__ V3 ray_dir(const RayPk &R) { return mk(R.dxy.x, R.dxy.y, R.dzz.x); }
 
@@ -657,35 +663,26 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
 
     for (;;) {
         if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(hit)); }
-        /* (A) shade the lanes whose cast is complete: one iteration of trace, shader.wgsl:118-133 */
+        /* (A) lanes whose cast is complete pick their closest hit; a miss ends the path with the
+         * sky term (shader.wgsl:128-132) */
+        float hit_t = PT_FAR;
+        int32_t hit_id = PT_NONE;
         if (hit) {
-            float t = sph_t;
-            int32_t id = sph_id;
-            V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
-            if (T.best_id != PT_NONE && T.best_t < t) { t = T.best_t; id = T.best_id; }
-            bool finished;
-            if (id != PT_NONE) {
-                Surface sf = surface_of(P, ro, rd, t, id);
-                bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
-                i++;
-                finished = i > P.max_bounce_count;            /* loop bound reached: no sky term */
-            } else {
-                if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
-                finished = true;
-            }
-            hit = false;
-            if (finished) {
+            hit_t = sph_t; hit_id = sph_id;
+            if (T.best_id != PT_NONE && T.best_t < hit_t) { hit_t = T.best_t; hit_id = T.best_id; }
+            if (hit_id == PT_NONE) {
+                if (P.use_env) light = light + environment_light<EXACT>(P, ray_dir(T.R)) * ray_color;
                 P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                hit = false;
                 idle = true;
-            } else {
-                raypk_set(T.R, ro, rd);
-                has_ray = true;
             }
         }
         /* (B) idle lanes pull new paths: one atomic per wave.  The queue is cut into 8 equal,
          * contiguous parts, one per XCD (consecutive paths belong to neighbouring pixels, so a
          * part is a compact piece of the image and the BVH nodes its rays visit stay in that
-         * XCD's 4 MiB L2).  A wave drains its own XCD's part first, then helps the others. */
+         * XCD's 4 MiB L2).  A wave drains its own XCD's part first, then helps the others.
+         * A new path starts as "cast complete" at its primary hit, iteration i = 0 of trace
+         * (shader.wgsl:117-127), and is shaded below together with the others. */
         unsigned long long need = __ballot(idle);
         if (need) {
             while (!drained) {
@@ -699,7 +696,6 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                     const uint32_t local = base + prefix_count(need);
                     if (local < q_len) {
                         const uint32_t item = q_start + local;
-                        /* start the path at its primary hit: iteration i = 0 of trace (shader.wgsl:117-127) */
                         /* queue index -> (hit pixel, frame of the batch, sample) */
                         uint32_t hf = fast_div(item, P.div_rpp);
                         uint32_t s = item - hf * rpp;
@@ -710,22 +706,17 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                         uint32_t py = fast_div(h.pixel, P.div_width);
                         uint32_t px = h.pixel - py * P.width;
                         uint32_t pixel_index;
-                        V3 ro = ld3(P.cam_pos), rd;
+                        V3 rd;
                         primary_ray(P, px, py, rd, pixel_index);
+                        raypk_set_od(T.R, ld3(P.cam_pos), rd);
                         /* shader.wgsl:100 and :121, folded: the frame term is the same for every bounce */
                         seed = pixel_index + s * 248135u + frame_count * 393939123u;
                         light = mk(0.0f, 0.0f, 0.0f);
                         ray_color = mk(1.0f, 1.0f, 1.0f);
-                        Surface sf = surface_of(P, ro, rd, h.distance, h.prim_id);
-                        bounce<EXACT>(P, sf, seed, 0u, ro, rd, light, ray_color);
-                        i = 1;
-                        if (i > P.max_bounce_count) {                           /* max_bounce_count == 0 */
-                            P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
-                        } else {
-                            raypk_set(T.R, ro, rd);
-                            idle = false;
-                            has_ray = true;
-                        }
+                        i = 0;
+                        hit_t = h.distance; hit_id = h.prim_id;
+                        idle = false;
+                        hit = true;
                     }
                 }
                 if (exhausted) {
@@ -735,6 +726,21 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                 if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
             }
             if (drained && idle) { idle = false; dead = true; }
+        }
+        /* (A, continued) one "hit" iteration of trace for old and new paths alike, shader.wgsl:119-127 */
+        if (hit) {
+            V3 ro = ray_origin(T.R), rd = ray_dir(T.R);
+            Surface sf = surface_of(P, ro, rd, hit_t, hit_id);
+            bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
+            i++;
+            hit = false;
+            if (i > P.max_bounce_count) {                 /* loop bound reached: no sky term */
+                P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                idle = true;                              /* refilled in the next round */
+            } else {
+                raypk_set(T.R, ro, rd);
+                has_ray = true;
+            }
         }
         /* (C) new rays: spheres first (shader.wgsl:144-154), then set up the traversal */
         if (has_ray) {

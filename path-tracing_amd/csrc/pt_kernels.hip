@@ -256,11 +256,12 @@ __device__ __forceinline__ void trav_begin(const PTKernelParams &P, uint32_t sta
  * (entries 64 dwords apart, so a wave's pushes and pops never bank-conflict).
  *
  * Measured on MI355X and rejected: (1) a copy of the top ~1000 records of the tree in LDS (40 % of
- * all visits) - no gain; (2) quad-cooperative record fetches through LDS-DMA, which cut the L1 tag
- * lookups per step by 4 - 20 % slower (longer dependent chain per step); (3) prefetching both
- * children while the box tests run - 25 % slower.  The traversal is bound by the latency of its
- * dependent load -> test -> pop chain at the occupancy the register file allows, with the vector
- * ALU, the vector-memory pipeline and the L1 each about half busy.
+ * all visits) - no gain; (2) quad-cooperative record fetches through LDS-DMA - 20 % slower (longer
+ * dependent chain per step); (3) prefetching both children while the box tests run - 25 % slower.
+ * Probes that add work without changing results (PT_ABL_* below) put the cost of the four 16-byte
+ * loads of a visit at about 27 % of the kernel and that of the two box tests at about 16 %; the
+ * loads cost the same whether they hit or miss and whether they fetch 8 or 16 bytes, so it is the
+ * number of gather instructions that counts.
  */
 extern __shared__ uint32_t pt_lds[];
 __device__ __forceinline__ uint32_t lane_id();
@@ -302,7 +303,8 @@ __device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
 template <bool FAST, bool COUNT, bool SPILL>
 __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, Trav &T, Counters &cn) {
     const PTInnerRecord *rec = P.inner + T.cur;
-    float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2], q3 = rec->q[3];
+    float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2];
+    const uint2 refs = *reinterpret_cast<const uint2 *>(&rec->q[3]);        /* only 8 of the last 16 bytes are used */
     float dst_a, dst_b;
     ray_box2<FAST>(T.R, q0, q1, q2, dst_a, dst_b);
 #ifdef PT_ABL_DIV2      /* sensitivity probe: a second box test whose result cannot change anything */
@@ -324,7 +326,7 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
     }
 #endif
     if (COUNT) cn.boxes += 2;
-    uint32_t ref_a = __float_as_uint(q3.x), ref_b = __float_as_uint(q3.y);
+    uint32_t ref_a = refs.x, ref_b = refs.y;
     float dst_near, dst_far;
     uint32_t ref_near, ref_far;
     if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }

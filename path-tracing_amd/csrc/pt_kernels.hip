@@ -319,7 +319,13 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
 #endif
 #ifdef PT_ABL_LOAD2     /* sensitivity probe: four more 16-byte loads, PT_ABL_LOAD2 records back */
     {
+#ifdef PT_ABL_LOAD2_UNIFORM     /* the same record for all lanes, still through the vector path */
+        uint32_t first_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.cur);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(first_cur) : "s"(first_cur));
+        const PTInnerRecord *r2 = P.inner + first_cur;
+#else
         const PTInnerRecord *r2 = P.inner + (T.cur >= PT_ABL_LOAD2 ? T.cur - PT_ABL_LOAD2 : T.cur);
+#endif
         float4 e0 = r2->q[0], e1 = r2->q[1], e2 = r2->q[2], e3 = r2->q[3];
         float s = e0.x + e1.x + e2.x + e3.x;
         dst_a = fmin_(dst_a, fabsf(s) + 3.0e38f);

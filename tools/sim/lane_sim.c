@@ -80,6 +80,8 @@ typedef struct {
                              2 slots: parked paths waiting for shading before a shading round runs */
     int swap_min;         /* 2 slots: idle lanes (with a ready parked path) before a swap round runs */
     int leaf_min, leaf_shift;
+    int leaf_period;      /* > 0: leaves run in every leaf_period-th step only (leaf_min/leaf_shift unused) */
+    int steps_per_check;  /* steps between two looks at the swap / refill conditions */
     double cost_inner, cost_leaf, cost_shade, cost_swap;
 } sim_policy;
 
@@ -116,8 +118,8 @@ int sim_run(const sim_policy *pol, sim_result *out) {
         /* ---- shading / refill round ---- */
         int shade_lanes = 0;
         for (int i = 0; i < 64; i++) {
-            /* a paths with a complete cast */
-            if (l[i].a_path >= 0 && l[i].a_pos == (int)g_casts[g_paths[l[i].a_path].first_cast + l[i].a_cast].n_visits) {
+            /* a paths with a complete cast (one path per lane only: with a parked path the lane swaps instead) */
+            if (pol->slots == 1 && l[i].a_path >= 0 && l[i].a_pos == (int)g_casts[g_paths[l[i].a_path].first_cast + l[i].a_cast].n_visits) {
                 shade_lanes++;
                 if (!advance_cast(l[i].a_path, &l[i].a_cast)) l[i].a_path = -1;
                 l[i].a_pos = 0;
@@ -127,13 +129,13 @@ int sim_run(const sim_policy *pol, sim_result *out) {
                 if (!advance_cast(l[i].b_path, &l[i].b_cast)) l[i].b_path = -1; else l[i].b_ready = 1;
             }
             /* paths without any bounce cast are finished at refill time */
-            while (l[i].a_path < 0) { int p = next_path(&head); if (p < 0) break; if (g_paths[p].n_casts) { l[i].a_path = p; l[i].a_cast = 0; l[i].a_pos = 0; } }
+            if (pol->slots == 1) while (l[i].a_path < 0) { int p = next_path(&head); if (p < 0) break; if (g_paths[p].n_casts) { l[i].a_path = p; l[i].a_cast = 0; l[i].a_pos = 0; } }
             if (pol->slots == 2) while (l[i].b_path < 0) { int p = next_path(&head); if (p < 0) break; if (g_paths[p].n_casts) { l[i].b_path = p; l[i].b_cast = 0; l[i].b_ready = 1; } }
         }
         out->shade_rounds++; out->shade_lanes += shade_lanes;
         wave_time[w] += pol->cost_shade;
         /* ---- traversal loop ---- */
-        for (;;) {
+        for (int step_no = 0;; step_no++) {
             int trav = 0, waiting_a = 0, waiting_b = 0, swappable = 0, n_inner = 0, n_leaf = 0;
             for (int i = 0; i < 64; i++) {
                 int a_done = 1;
@@ -142,34 +144,53 @@ int sim_run(const sim_policy *pol, sim_result *out) {
                     if (l[i].a_pos < (int)c->n_visits) { a_done = 0; trav++; if (g_visits[c->first_visit + l[i].a_pos]) n_leaf++; else n_inner++; }
                     else waiting_a++;
                 }
-                if (pol->slots == 2 && l[i].b_path >= 0) { if (!l[i].b_ready) waiting_b++; else if (a_done) swappable++; }
-            }
-            if (pol->slots == 1) {
-                if (!trav || waiting_a >= pol->refill_min) break;
-            } else {
-                if (swappable >= pol->swap_min || (!trav && swappable)) {
-                    /* swap round: idle lanes exchange their finished (or absent) path with the ready parked one */
-                    for (int i = 0; i < 64; i++) {
-                        if (l[i].b_path < 0 || !l[i].b_ready) continue;
-                        int a_done = 1;
-                        if (l[i].a_path >= 0) {
-                            const cast_t *c = &g_casts[g_paths[l[i].a_path].first_cast + l[i].a_cast];
-                            if (l[i].a_pos < (int)c->n_visits) a_done = 0;
-                        }
-                        if (!a_done) continue;
-                        int ap = l[i].a_path, ac = l[i].a_cast;
-                        l[i].a_path = l[i].b_path; l[i].a_cast = l[i].b_cast; l[i].a_pos = 0;
-                        l[i].b_path = ap; l[i].b_cast = ac; l[i].b_ready = 0;      /* parked, waits for shading (or empty) */
-                        out->swap_lanes++;
-                    }
-                    out->swap_rounds++;
-                    wave_time[w] += pol->cost_swap;
-                    continue;
+                if (pol->slots == 2) {
+                    if (l[i].b_path >= 0) { if (!l[i].b_ready) waiting_b++; else if (a_done) swappable++; }
+                    else if (a_done && l[i].a_path >= 0) swappable++;      /* nothing parked: the finished cast moves over */
                 }
-                if (!trav || waiting_a + waiting_b >= pol->refill_min) break;
+            }
+            const int check = pol->steps_per_check <= 1 || step_no % pol->steps_per_check == 0;
+            if (check) {
+                if (pol->slots == 1) {
+                    if (!trav || waiting_a >= pol->refill_min) break;
+                } else {
+                    if (swappable >= pol->swap_min || (!trav && swappable)) {
+                        /* swap round: idle lanes exchange their finished (or absent) path with the ready parked one */
+                        for (int i = 0; i < 64; i++) {
+                            if (l[i].b_path >= 0 && !l[i].b_ready) continue;
+                            if (l[i].b_path < 0 && l[i].a_path < 0) continue;
+                            int a_done = 1;
+                            if (l[i].a_path >= 0) {
+                                const cast_t *c = &g_casts[g_paths[l[i].a_path].first_cast + l[i].a_cast];
+                                if (l[i].a_pos < (int)c->n_visits) a_done = 0;
+                            }
+                            if (!a_done) continue;
+                            int ap = l[i].a_path, ac = l[i].a_cast;
+                            l[i].a_path = l[i].b_path; l[i].a_cast = l[i].b_cast; l[i].a_pos = 0;
+                            l[i].b_path = ap; l[i].b_cast = ac; l[i].b_ready = 0;      /* parked, waits for shading (or empty) */
+                            out->swap_lanes++;
+                        }
+                        out->swap_rounds++;
+                        wave_time[w] += pol->cost_swap;
+                        step_no = -1;
+                        continue;
+                    }
+                    /* lanes that cannot proceed: parked path waits for shading, or nothing parked and the queue has work */
+                    int stuck = 0;
+                    for (int i = 0; i < 64; i++) {
+                        int b_wait = l[i].b_path >= 0 ? !l[i].b_ready : (head < g_npath);
+                        if (b_wait) stuck++;
+                    }
+                    if (!trav || stuck >= pol->refill_min) break;
+                }
+            } else if (!trav) {
+                wave_time[w] += 0.3 * pol->cost_inner;     /* an empty step until the next check */
+                continue;
             }
             /* one wave step */
-            int run_leaves = !n_inner || n_leaf >= pol->leaf_min || (n_leaf << pol->leaf_shift) >= n_leaf + n_inner;
+            int run_leaves;
+            if (pol->leaf_period > 0) run_leaves = (step_no % pol->leaf_period) == pol->leaf_period - 1;
+            else run_leaves = !n_inner || n_leaf >= pol->leaf_min || (n_leaf << pol->leaf_shift) >= n_leaf + n_inner;
             for (int i = 0; i < 64; i++) {
                 if (l[i].a_path < 0) continue;
                 const cast_t *c = &g_casts[g_paths[l[i].a_path].first_cast + l[i].a_cast];
@@ -178,7 +199,7 @@ int sim_run(const sim_policy *pol, sim_result *out) {
                 if (!leaf || run_leaves) l[i].a_pos++;
             }
             out->steps++; out->inner_lane_steps += n_inner;
-            if (n_inner) wave_time[w] += pol->cost_inner;
+            wave_time[w] += n_inner ? pol->cost_inner : 0.3 * pol->cost_inner;
             if (run_leaves && n_leaf) { out->leaf_runs++; out->leaf_lane_steps += n_leaf; wave_time[w] += pol->cost_leaf; }
         }
         /* finished? */

@@ -16,7 +16,7 @@ from path_tracing_amd import scenes  # noqa: E402
 
 class Policy(C.Structure):
     _fields_ = [("waves", C.c_int), ("slots", C.c_int), ("refill_min", C.c_int), ("swap_min", C.c_int),
-                ("leaf_min", C.c_int), ("leaf_shift", C.c_int),
+                ("leaf_min", C.c_int), ("leaf_shift", C.c_int), ("leaf_period", C.c_int), ("steps_per_check", C.c_int),
                 ("cost_inner", C.c_double), ("cost_leaf", C.c_double), ("cost_shade", C.c_double), ("cost_swap", C.c_double)]
 
 
@@ -45,7 +45,7 @@ def main():
     waves = int(os.environ.get("WAVES", "40"))
 
     def run(**kw):
-        base = dict(waves=waves, slots=1, refill_min=58, swap_min=16, leaf_min=8, leaf_shift=2,
+        base = dict(waves=waves, slots=1, refill_min=60, swap_min=16, leaf_min=8, leaf_shift=2, leaf_period=3, steps_per_check=6,
                     cost_inner=1.0, cost_leaf=1.0, cost_shade=6.0, cost_swap=1.0)
         base.update(kw)
         p = Policy(**base)
@@ -59,12 +59,11 @@ def main():
             r.leaf_lane_steps / max(1, r.leaf_runs), r.shade_rounds, r.shade_lanes / max(1, r.shade_rounds),
             r.swap_rounds, r.swap_lanes / max(1, r.swap_rounds)))
 
-    for cs in (6.0, 4.0, 3.0, 2.0):
-        best = min(((run(refill_min=rm, cost_shade=cs).time, rm) for rm in (24, 32, 40, 48, 52, 56, 58, 60)))
-        print("1 slot cost_shade=%.1f: best refill_min=%d time %.0f" % (cs, best[1], best[0]))
-    for cl in (1.0, 0.5):
-        for lm, ls in ((8, 2), (8, 0), (16, 2), (4, 1), (64, 0), (1, 0)):
-            show("1 slot leaf cost %.1f leaf_min=%d shift=%d" % (cl, lm, ls), run(cost_leaf=cl, leaf_min=lm, leaf_shift=ls, refill_min=56))
+    for rm in (52, 56, 60, 62):
+        show("1 slot refill_min=%d" % rm, run(refill_min=rm, cost_leaf=0.8))
+    for sm in (4, 8, 16, 24):
+        for rm in (32, 48, 56, 60):
+            show("2 slots swap_min=%d refill_min=%d" % (sm, rm), run(slots=2, swap_min=sm, refill_min=rm, cost_leaf=0.8, cost_shade=5.0, cost_swap=1.0))
 
 
 if __name__ == "__main__":

@@ -71,6 +71,68 @@ int sim_profile(const orc_params *p, const orc_scene *s, const float cam[3], con
     return (int)g_npath;
 }
 
+/* How many inner-node visits are "stale": the node was pushed as a far child, and by the time it is
+ * popped the best hit is already nearer than the node's entry distance.  out = {inner visits, stale
+ * inner visits, leaf visits, stale leaf visits} over the bounce casts of the same paths as
+ * sim_profile. */
+static void count_stale(const orc_params *p, const orc_scene *s, orc_v3 o, orc_v3 d, uint64_t out[4]) {
+    int32_t node_stack[ORC_MAX_STACK]; float dst_stack[ORC_MAX_STACK];
+    int sp = 0;
+    node_stack[sp] = 0; dst_stack[sp++] = -1.0f;
+    float best = ORC_FAR;
+    while (sp > 0) {
+        sp--;
+        int32_t ni = node_stack[sp]; float nd = dst_stack[sp];
+        const float *node = s->bvh + 9 * (size_t)ni;
+        int stale = nd >= best;
+        if (node[8] == 0.0f) {
+            out[2]++; out[3] += stale;
+            uint32_t first = (uint32_t)node[6], end = (uint32_t)(node[6] + node[7]);
+            for (uint32_t i = first; i < end; i++) {
+                orc_hit th;
+                ray_triangle(p, o, d, s->triangles + 9 * (size_t)i, &th);
+                if (th.did_hit && th.distance < best) best = th.distance;
+            }
+        } else {
+            out[0]++; out[1] += stale;
+            int32_t ca = (int32_t)node[8], cb = ca + 1;
+            float da = ray_box(o, d, s->bvh + 9 * (size_t)ca), db = ray_box(o, d, s->bvh + 9 * (size_t)cb);
+            float dn, df; int32_t cn, cf;
+            if (da < db) { dn = da; df = db; cn = ca; cf = cb; } else { dn = db; df = da; cn = cb; cf = ca; }
+            if (df < best) { node_stack[sp] = cf; dst_stack[sp++] = df; }
+            if (dn < best) { node_stack[sp] = cn; dst_stack[sp++] = dn; }
+        }
+    }
+}
+
+int sim_stale(const orc_params *p, const orc_scene *s, const float cam[3], const float rot[3],
+              uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t frame, uint64_t out[4]) {
+    memset(out, 0, 4 * sizeof(uint64_t));
+    g_recording = 0;
+    for (uint32_t y = y0; y < y0 + h; y++) for (uint32_t x = x0; x < x0 + w; x++) {
+        float o[3], d[3]; uint32_t pixel_index;
+        orc_primary_ray(p, cam, rot, x, y, o, d, &pixel_index);
+        for (uint32_t smp = 0; smp < p->rays_per_pixel; smp++) {
+            uint32_t seed = pixel_index + smp * 248135u;
+            orc_v3 ro = from3(o), rd = from3(d);
+            for (uint32_t i = 0; i <= p->max_bounce_count; i++) {
+                orc_hit hit;
+                float o3[3] = {ro.x, ro.y, ro.z}, d3[3] = {rd.x, rd.y, rd.z};
+                if (i > 0) count_stale(p, s, ro, rd, out);
+                orc_calculate_ray_collision(p, s, o3, d3, &hit, NULL);
+                if (!hit.did_hit) break;
+                ro = hit.position;
+                uint32_t rs = seed + i * 12345u + frame * 393939123u;
+                orc_v3 diffuse_dir = vnormalize(vadd(hit.normal, random_direction(rs)));
+                float dn2 = 2.0f * vdot(hit.normal, rd);
+                orc_v3 specular_dir = vsub(rd, vscale(hit.normal, dn2));
+                rd = lerp3(diffuse_dir, specular_dir, hit.smoothness);
+            }
+        }
+    }
+    return 0;
+}
+
 void sim_sizes(uint64_t out[3]) { out[0] = g_npath; out[1] = g_ncast; out[2] = g_nvis; }
 
 typedef struct {

@@ -6,9 +6,11 @@
 A "step" is one complete render of the configuration (default: BASELINE config 4,
 dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
 max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
-one process per GPU with torch.distributed.run; frames are sharded over ranks and
-the accumulation buffers are summed with one RCCL all-reduce per step (strong
-scaling: total samples fixed).  Rank 0 prints ONE JSON line.
+one process per GPU with torch.distributed.run; the image is sharded over ranks in
+8x8-pixel tiles (every rank renders all frames of its tiles, running mean as on one
+GPU) and the zero-initialised buffers are assembled with one RCCL sum all-reduce per
+step (strong scaling: total samples fixed; the result equals the single-GPU image
+bit for bit).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     - path (bounce) kernel: algorithmic bytes of the casts it executes
@@ -56,10 +58,18 @@ def main():
     if args.gpus != world:
         if args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one process per GPU)")
+    # PT_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo, to rehearse the N > 1 code path
+    # on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
+    rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
     from path_tracing_amd import scenes
@@ -129,7 +139,7 @@ def main():
                 "resolution": [W, H], "spp": spp, "frames": n_frames, "rays_per_pixel": rpp,
                 "max_bounce_count": cfg["max_bounce_count"], "triangles": int(len(tris)),
                 "bvh_nodes": int(len(bvh)), "bvh_depth": info["bvh_depth"], "spheres": int(len(spheres)),
-                "parallelism": "frames sharded over %d GPU(s), one RCCL sum all-reduce per step" % world
+                "parallelism": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum all-reduce per step" % world
                                if world > 1 else "single GPU, running mean",
             },
             "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])
@@ -143,11 +153,9 @@ def main():
                 "traffic": None, "kernel": "path_kernel"}
         if not args.no_count and timing["frames"]:
             rc = make_renderer(pkg.PT_FLAG_COUNT_WORK)
-            frames_local = len(range(rank, n_frames, world))
-            if world > 1:
-                rc.render_frames_sum(rank, frames_local, world)
-            else:
-                rc.render_frames(0, n_frames)
+            frames_local = n_frames
+            rc.set_pixel_shard(rank, world)          # the launches this rank timed
+            rc.render_frames(0, n_frames)
             cnt = rc.counters()
             rc.close()
             S = len(spheres)
@@ -158,7 +166,7 @@ def main():
             avg_ms = timing["path_ms"] / timing["batches"]
             achieved = per_launch / (avg_ms * 1e-3) / 1e9
             all_bytes = 36 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 48 * S * cnt["ray_casts"] \
-                + 32 * W * H * frames_local
+                + 32 * W * H * frames_local // world
             roof.update({
                 "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms,
@@ -168,11 +176,11 @@ def main():
                 "tri_tests_per_cast": cnt["path_kernel_tri_tests"] / max(1, cnt["path_kernel_ray_casts"]),
                 "frac_of_l2_peak": achieved / L2_PEAK_GBS, "frac_of_mall_peak": achieved / MALL_PEAK_GBS,
                 "whole_frame_algorithmic_bytes": all_bytes / frames_local,
-                "reference_ray_casts_per_step": cnt["ray_casts"] * (world if world > 1 else 1),
-                "rays_per_second": cnt["ray_casts"] / frames_local * n_frames * args.steps / elapsed,
+                "reference_ray_casts_per_step": cnt["ray_casts"] * world,       # rank 0's share x ranks
+                "rays_per_second": cnt["ray_casts"] * world * args.steps / elapsed,
             })
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and world == 1:      # collected for the single-GPU launch shape
                 with open(tpath) as f:
                     tj = json.load(f)
                 if tj.get("workload") == cfg["name"]:

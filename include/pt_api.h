@@ -187,6 +187,14 @@ int pt_reset_timing(pt_ctx *ctx);
  * nodes and leaves. */
 int pt_scene_info(pt_ctx *ctx, uint32_t *bvh_depth, uint32_t *inner_nodes, uint32_t *leaves);
 
+/* Pixel sharding for multi-GPU renders: after this call the context renders only the 8x8-pixel
+ * tiles with (tile_x + tile_y) % world_size == rank and leaves every other pixel of the
+ * accumulation buffer untouched.  Each pixel keeps the reference's running mean (shader.wgsl:
+ * 104-106) on the rank that owns it, so adding the zero-initialised buffers of all ranks gives
+ * the single-GPU image bit for bit.  (0, 1) restores the whole image.  pt_primary_hits always
+ * covers the whole image.  No reference counterpart (the reference is single-GPU). */
+int pt_set_pixel_shard(pt_ctx *ctx, uint32_t rank, uint32_t world_size);
+
 /* Replaces Rust drop of State. */
 void pt_destroy(pt_ctx *ctx);
 

@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
-    "pt_update_camera", "pt_host_rotate_vector",
+    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -109,6 +109,7 @@ def load_library():
     L.pt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.pt_render_frames_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.pt_scale_accum.argtypes = [C.c_void_p, C.c_float]
+    L.pt_set_pixel_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.pt_read_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
     L.pt_reset_accum.argtypes = [C.c_void_p]
     L.pt_bind_accum.argtypes = [C.c_void_p, C.c_void_p]
@@ -321,6 +322,10 @@ class Renderer:
 
     def render_frames_sum(self, first_frame_count, n_frames, frame_stride=1):
         self._check(self._L.pt_render_frames_sum(self._ctx, int(first_frame_count), int(n_frames), int(frame_stride)))
+
+    def set_pixel_shard(self, rank, world_size):
+        """Render only the 8x8 tiles with (tile_x + tile_y) % world_size == rank (multi-GPU)."""
+        self._check(self._L.pt_set_pixel_shard(self._ctx, int(rank), int(world_size)))
 
     def scale_accum(self, s):
         self._check(self._L.pt_scale_accum(self._ctx, float(s)))

@@ -55,6 +55,7 @@ struct pt_ctx {
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
     int stack_entries = 0;
     bool fast_div = false;
+    uint32_t shard_rank = 0, shard_world = 1;
     uint32_t refill_min = 60;
     uint32_t leaf_min = 8;
     uint32_t leaf_shift = 2;
@@ -242,6 +243,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.div_rpp = pt_fastdiv_make(p.rays_per_pixel);
     k.div_batch = pt_fastdiv_make(batch_frames);
     k.accum_mode = accum_mode;
+    k.shard_rank = c->shard_rank; k.shard_world = c->shard_world;
     k.width_f = (float)p.width; k.height_f = (float)p.height;
     /* vs_main, shader.wgsl:36-37,68-69.  fov is a const-expression of abstract
      * floats (f64, rounded once); tan is taken in double and rounded once. */
@@ -518,6 +520,13 @@ int pt_render_frames(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames) {
 int pt_render_frames_sum(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames, uint32_t frame_stride) {
     if (c && frame_stride == 0) return fail(c, PT_EINVAL, "frame_stride must be >= 1");
     return render_impl(c, first_frame_count, n_frames, frame_stride, 1);
+}
+
+int pt_set_pixel_shard(pt_ctx *c, uint32_t rank, uint32_t world_size) {
+    if (!c) return PT_EINVAL;
+    if (world_size == 0 || rank >= world_size || world_size > 4096) return fail(c, PT_EINVAL, "need 0 <= rank < world_size <= 4096");
+    c->shard_rank = rank; c->shard_world = world_size;
+    return PT_OK;
 }
 
 int pt_scale_accum(pt_ctx *c, float s) {

@@ -70,6 +70,7 @@ struct PTKernelParams {
     uint32_t batch_frames;         /* frames rendered by this batch of launches */
     PTFastDiv div_width;           /* pixel -> row */
     PTFastDiv div_rpp, div_batch;  /* queue index = (hit * batch_frames + frame) * rays_per_pixel + sample */
+    uint32_t shard_rank, shard_world;   /* pixel sharding: this context renders the 8x8 tiles with (tile_x + tile_y) % world == rank */
     uint32_t accum_mode;           /* 0: running mean (shader.wgsl:104-106), 1: add the frame mean */
     float width_f, height_f, screen_w, screen_h;
     float cam_pos[3];

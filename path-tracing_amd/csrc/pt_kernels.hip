@@ -33,6 +33,8 @@
 #define PT_BOX_MISS 999999999.0f   /* shader.wgsl:254 */
 #define PT_PI 3.14159f             /* shader.wgsl:36,365 */
 #define PT_NONE INT32_MIN
+#define PT_PIXEL_MISS 0xffffffffu       /* pixel_hit: primary ray hit nothing */
+#define PT_PIXEL_NOT_MINE 0xfffffffeu   /* pixel_hit: pixel belongs to another rank's shard */
 
 #define PT_WAVES_PER_BLOCK 4
 #define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
@@ -561,7 +563,11 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     /* block = 16x16 pixels, wave = 8x8 tile */
     const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool valid = px < P.width && py < P.height;
+    const bool inside = px < P.width && py < P.height;
+    /* pixel sharding: a wave's 8x8 tile belongs to rank (tile_x + tile_y) % world; the ids/distance
+     * output (AOV) always covers the whole image */
+    const bool mine = AOV || P.shard_world <= 1u || ((px >> 3) + (py >> 3)) % P.shard_world == P.shard_rank;
+    const bool valid = inside && mine;
     Counters cn = {0, 0, 0, 0};
 
     V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
@@ -578,7 +584,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const bool hit = valid && id != PT_NONE;
     /* compact the hit pixels of this wave into the global list: one atomic per wave */
     unsigned long long mask = __ballot(hit);
-    uint32_t hit_index = 0xffffffffu;
+    uint32_t hit_index = PT_PIXEL_MISS;
     if (mask) {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(&P.ctrl->hit_count, (uint32_t)__popcll(mask));
@@ -590,6 +596,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
             P.hits[hit_index] = r;
         }
     }
+    if (inside && !mine) P.pixel_hit[pixel] = PT_PIXEL_NOT_MINE;     /* the resolve kernel leaves it alone */
     if (valid) {
         P.pixel_hit[pixel] = hit_index;
         if (!hit) {
@@ -823,7 +830,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
         }
         P.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
     }
-    if (t < P.width * P.height && P.pixel_hit[t] == 0xffffffffu) {
+    if (t < P.width * P.height && P.pixel_hit[t] == PT_PIXEL_MISS) {
         float4 a4 = P.accum[t];
         V3 acc = mk(a4.x, a4.y, a4.z);
         float4 c = P.pixel_const[t];

@@ -1,4 +1,16 @@
-"""Multi-GPU rendering: one process per GPU, frames sharded across ranks.
+"""Multi-GPU rendering: one process per GPU, the image or the frames sharded across ranks.
+
+Two ways to split a render, both with the scene replicated on every GPU and ONE collective per
+render (RCCL over xGMI when the process group's backend is "nccl"):
+
+pixels (default)  rank r renders the 8x8-pixel tiles with (tile_x + tile_y) % N == r for ALL
+                  frames, keeping the reference's running mean per pixel (pt_set_pixel_shard +
+                  pt_render_frames); the other pixels of its zero-initialised buffer stay 0, so a
+                  sum all-reduce assembles the image.  x + 0 is exact: the result equals the
+                  single-GPU image bit for bit.  The primary-ray pass is sharded too.
+frames            described below; kept for renders whose frames outnumber their pixels.
+
+Frame sharding:
 
 The reference is single-GPU.  Its unit of accumulation is the frame
 (src/main.rs:448-452,510; shader.wgsl:104-106), and every (pixel, frame, sample)
@@ -33,15 +45,45 @@ def render_sharded(render_sum, all_reduce, scale, first_frame, n_frames, rank, w
     scale(1.0 / float(n_frames))
 
 
+TILE = 8      # pixel sharding works on the primary kernel's 8x8 wave tiles
+
+
+def tile_owner(x, y, world_size):
+    """Rank that renders pixel (x, y) under pixel sharding (same rule as pt_set_pixel_shard)."""
+    return ((x // TILE) + (y // TILE)) % world_size
+
+
+def owner_mask(width, height, rank, world_size):
+    """(height, width) boolean array: True where `rank` owns the pixel."""
+    import numpy as np
+    tx = np.arange(width) // TILE
+    ty = np.arange(height) // TILE
+    return (tx[None, :] + ty[:, None]) % world_size == rank
+
+
+def render_pixel_sharded(render_owned, all_reduce, first_frame, n_frames):
+    """Generic driver of pixel sharding, independent of where the buffer lives.
+
+    render_owned(first, count): running mean of the frames over the rank's own pixels, other
+                                pixels of the (zeroed) buffer untouched
+    all_reduce():               sums the buffers of all ranks in place
+    """
+    render_owned(first_frame, n_frames)
+    all_reduce()
+
+
 class ShardedRenderer:
     """A Renderer whose accumulation buffer is a torch CUDA tensor so that
     torch.distributed (backend "nccl" = RCCL) can reduce it in place."""
 
-    def __init__(self, renderer, rank, world_size, group=None):
+    def __init__(self, renderer, rank, world_size, group=None, mode="pixels"):
         import torch
 
+        if mode not in ("pixels", "frames"):
+            raise ValueError("mode must be 'pixels' or 'frames'")
         self.r = renderer
-        self.rank, self.world_size, self.group = rank, world_size, group
+        self.rank, self.world_size, self.group, self.mode = rank, world_size, group, mode
+        renderer.set_pixel_shard(*((rank, world_size) if mode == "pixels" else (0, 1)))
         dev = torch.device("cuda", torch.cuda.current_device())
         self.buffer = torch.zeros(renderer.height * renderer.width * 4, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
@@ -60,9 +102,12 @@ class ShardedRenderer:
                 dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.synchronize()
 
-        render_sharded(lambda f, c, s: self.r.render_frames_sum(f, c, s), all_reduce,
-                       lambda s: self.r.scale_accum(s), first_frame, n_frames, self.rank, self.world_size)
-        self.r.synchronize()
+        if self.mode == "pixels":
+            render_pixel_sharded(lambda f, c: self.r.render_frames(f, c), all_reduce, first_frame, n_frames)
+        else:
+            render_sharded(lambda f, c, s: self.r.render_frames_sum(f, c, s), all_reduce,
+                           lambda s: self.r.scale_accum(s), first_frame, n_frames, self.rank, self.world_size)
+            self.r.synchronize()
 
     def image(self):
         return self.buffer.view(self.r.height, self.r.width, 4)

@@ -65,6 +65,63 @@ def _worker(rank, world, port, n_frames, out_dir):
     dist.destroy_process_group()
 
 
+def test_tile_ownership_partitions_the_image(pkg):
+    from path_tracing_amd.distributed import owner_mask, tile_owner
+    for w, h in [(1, 1), (17, 9), (96, 54), (130, 65)]:
+        for world in [1, 2, 3, 8]:
+            masks = [owner_mask(w, h, r, world) for r in range(world)]
+            assert np.array_equal(sum(m.astype(int) for m in masks), np.ones((h, w), int))
+            assert masks[tile_owner(w - 1, h - 1, world)][h - 1, w - 1]
+    # neighbouring tiles go to different ranks, so every rank sees every part of the image
+    m = owner_mask(1920, 1080, 3, 8)
+    assert abs(m.mean() - 1 / 8) < 0.002 and m[:540].mean() > 0.12 and m[:, :960].mean() > 0.12
+
+
+def _pixel_worker(rank, world, port, n_frames, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import owner_mask, render_pixel_sharded
+    oracle = entry.load_oracle_module().Oracle(shared_math=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    buf = torch.zeros(27, 48, 4, dtype=torch.float32)
+    arr = buf.numpy()
+
+    def render_owned(first, count):
+        # the oracle renders whole images; keeping only the rank's tiles is what the device
+        # does when pt_set_pixel_shard is in force
+        full = oracle.render_frames(p, sc, cfg["camera_position"], cfg["camera_rotation"], first, count, nthreads=2)
+        arr[owner_mask(48, 27, rank, world)] = full[owner_mask(48, 27, rank, world)]
+
+    render_pixel_sharded(render_owned, lambda: dist.all_reduce(buf), 0, n_frames)
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank), arr)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pixel_sharded_render_is_the_single_rank_image(tmp_path, oracle_shared, scenes):
+    import torch.multiprocessing as mp
+    n_frames = 3
+    mp.spawn(_pixel_worker, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    mean = oracle_shared.render_frames(p, sc, cfg["camera_position"], cfg["camera_rotation"], 0, n_frames)
+    assert np.array_equal(r0.view(np.uint32), mean.view(np.uint32))          # adding zeros is exact
+
+
 @pytest.mark.parametrize("n_frames", [4, 3])
 def test_two_rank_sharded_render_matches_single_rank(tmp_path, oracle_shared, scenes, n_frames):
     import torch.multiprocessing as mp

@@ -1,5 +1,6 @@
-"""Two processes, one MI355X: the frame-sharded render path (ShardedRenderer: torch tensor bound as
-accumulation buffer, pt_render_frames_sum, all-reduce, scale) end to end on the GPU.  The box has a
+"""Two processes, one MI355X: the sharded render paths (ShardedRenderer: torch tensor bound as
+accumulation buffer; pixel tiles with pt_set_pixel_shard + pt_render_frames, or frames with
+pt_render_frames_sum + scale; one all-reduce) end to end on the GPU.  The box has a
 single GPU, so the two ranks share it and the process group uses gloo (RCCL refuses two ranks on one
 device); bench.py --gpus N runs the same code with backend nccl, one rank per GPU."""
 import os
@@ -21,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n_frames, out_dir):
+def _worker(rank, world, port, n_frames, out_dir, mode):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -39,7 +40,7 @@ def _worker(rank, world, port, n_frames, out_dir):
     with pkg.Renderer(p, device=0) as r:
         r.upload_scene(scenes.spheres_for("cfg1"), tris, bvh)
         r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
-        sh = ShardedRenderer(r, rank, world)
+        sh = ShardedRenderer(r, rank, world, mode=mode)
         sh.render(0, n_frames)
         sh.render(0, n_frames)          # a second render must start from a clean buffer
         img = sh.image().cpu().numpy()
@@ -48,10 +49,25 @@ def _worker(rank, world, port, n_frames, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu(tmp_path, oracle_shared, scenes):
+def test_two_ranks_one_gpu_pixel_shards(tmp_path, oracle_shared, scenes):
+    """Pixel sharding: every rank ends with the single-GPU running mean, bit for bit."""
     import torch.multiprocessing as mp
     n_frames = 5
-    mp.spawn(_worker, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), n_frames, str(tmp_path), "pixels"), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
+    assert np.array_equal(r0, r1)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=96, height=54, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    mean = oracle_shared.render_frames(p, sc, cfg["camera_position"], cfg["camera_rotation"], 0, n_frames)
+    assert np.array_equal(r0[..., :3].view(np.uint32), mean[..., :3].view(np.uint32))
+
+
+def test_two_ranks_one_gpu_frame_shards(tmp_path, oracle_shared, scenes):
+    import torch.multiprocessing as mp
+    n_frames = 5
+    mp.spawn(_worker, args=(2, _free_port(), n_frames, str(tmp_path), "frames"), nprocs=2, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npy"), np.load(tmp_path / "rank1.npy")
     assert np.array_equal(r0, r1)
     cfg = scenes.config(1)

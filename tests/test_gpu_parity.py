@@ -329,3 +329,41 @@ def test_full_size_configs_on_a_pixel_lattice(pkg, scenes, oracle_shared, n, ste
     assert want.shape[0] * want.shape[1] > 1000
     assert (want.sum(axis=-1) > 0).mean() > 0.5
     assert np.array_equal(bits(got), bits(want))
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_pixel_shards_add_up_to_the_unsharded_image(pkg, scenes, oracle_shared, world):
+    """pt_set_pixel_shard: every rank renders its 8x8 tiles only and leaves the rest of its zeroed
+    buffer alone; the sum of the buffers is the unsharded running mean bit for bit, the work
+    counters add up, and each rank's pixels are exactly its tiles."""
+    from path_tracing_amd.distributed import owner_mask
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH | pkg.PT_FLAG_COUNT_WORK,
+                            width=130, height=70, rays_per_pixel=2)
+    total = np.zeros((70, 130, 4), np.float32)
+    counts = {"ray_casts": 0, "box_tests": 0, "tri_tests": 0, "paths": 0}
+    with r:
+        for rank in range(world):
+            r.set_pixel_shard(rank, world)
+            r.reset_accum()
+            r.reset_counters()
+            r.render_frames(0, 3)
+            part = r.read_accum(4)
+            mask = owner_mask(130, 70, rank, world)
+            assert not part[~mask].any()
+            assert part[mask][..., :3].any()
+            total += part
+            c = r.counters()
+            for k in counts:
+                counts[k] += c[k]
+        r.set_pixel_shard(0, 1)
+        r.reset_counters()
+        r.render_frames(0, 3)
+        whole = r.read_accum(4)
+        cw = r.counters()
+        with pytest.raises(pkg.PtError):
+            r.set_pixel_shard(2, 2)
+    assert np.array_equal(bits(total), bits(whole))
+    oimg = oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 3)
+    assert np.array_equal(bits(whole[..., :3]), bits(oimg[..., :3]))
+    for k in counts:
+        assert counts[k] == cw[k], k

@@ -8,8 +8,8 @@ dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
 max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
 one process per GPU with torch.distributed.run; the image is sharded over ranks in
 8x8-pixel tiles (every rank renders all frames of its tiles, running mean as on one
-GPU) and the zero-initialised buffers are assembled with one RCCL sum all-reduce per
-step (strong scaling: total samples fixed; the result equals the single-GPU image
+GPU) and the zero-initialised buffers are assembled with one RCCL sum reduce to rank 0
+per step (strong scaling: total samples fixed; the result equals the single-GPU image
 bit for bit).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
@@ -92,7 +92,7 @@ def main():
 
     r = make_renderer()
     info = r.scene_info()
-    sharded = ShardedRenderer(r, rank, world) if world > 1 else None
+    sharded = ShardedRenderer(r, rank, world, collective="reduce") if world > 1 else None     # the image ends on rank 0
 
     def step():
         if sharded is not None:
@@ -139,7 +139,7 @@ def main():
                 "resolution": [W, H], "spp": spp, "frames": n_frames, "rays_per_pixel": rpp,
                 "max_bounce_count": cfg["max_bounce_count"], "triangles": int(len(tris)),
                 "bvh_nodes": int(len(bvh)), "bvh_depth": info["bvh_depth"], "spheres": int(len(spheres)),
-                "parallelism": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum all-reduce per step" % world
+                "parallelism": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world
                                if world > 1 else "single GPU, running mean",
             },
             "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])

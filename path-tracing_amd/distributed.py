@@ -76,11 +76,16 @@ class ShardedRenderer:
     """A Renderer whose accumulation buffer is a torch CUDA tensor so that
     torch.distributed (backend "nccl" = RCCL) can reduce it in place."""
 
-    def __init__(self, renderer, rank, world_size, group=None, mode="pixels"):
+    def __init__(self, renderer, rank, world_size, group=None, mode="pixels", collective="all_reduce"):
+        """collective: "all_reduce" leaves the image on every rank, "reduce" on rank 0 only (what a
+        host that displays or stores the image needs; half the traffic per link on a ring)."""
         import torch
 
         if mode not in ("pixels", "frames"):
             raise ValueError("mode must be 'pixels' or 'frames'")
+        if collective not in ("all_reduce", "reduce"):
+            raise ValueError("collective must be 'all_reduce' or 'reduce'")
+        self.collective = collective
         self.r = renderer
         self.rank, self.world_size, self.group, self.mode = rank, world_size, group, mode
         renderer.set_pixel_shard(*((rank, world_size) if mode == "pixels" else (0, 1)))
@@ -99,7 +104,10 @@ class ShardedRenderer:
         def all_reduce():
             self.r.synchronize()                  # kernels run on the library's own stream
             if self.world_size > 1:
-                dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
+                if self.collective == "reduce":
+                    dist.reduce(self.buffer, dst=0, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
                 torch.cuda.synchronize()
 
         if self.mode == "pixels":

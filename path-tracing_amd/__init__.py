@@ -359,10 +359,10 @@ class Renderer:
         return c.as_dict()
 
     def debug_stats(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self._L.pt_get_debug_stats(self._ctx, out))
         names = ["wave_clocks", "trav_clocks", "trav_steps", "inner_lanes", "leaf_lanes", "leaf_runs",
-                 "outer_iters", "shade_lanes"]
+                 "outer_iters", "shade_lanes", "longest_wave", "longest_tail", "tail_sum"]
         return dict(zip(names, [int(x) for x in out]))
 
     def reset_counters(self):

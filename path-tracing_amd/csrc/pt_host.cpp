@@ -613,7 +613,7 @@ int pt_get_counters(pt_ctx *c, pt_counters *out) {
     return PT_OK;
 }
 
-int pt_get_debug_stats(pt_ctx *c, uint64_t out[8]) {
+int pt_get_debug_stats(pt_ctx *c, uint64_t out[16]) {
     if (!c) return PT_EINVAL;
     if (!out) return fail(c, PT_EINVAL, "out is NULL");
     if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
@@ -622,6 +622,11 @@ int pt_get_debug_stats(pt_ctx *c, uint64_t out[8]) {
     unsigned long long h[24];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[8 + i];
+    out[8] = h[16];                 /* longest wave lifetime */
+    out[9] = h[17];                 /* longest time a wave went on after it found the queue empty */
+    out[10] = h[20];                /* that time summed over waves */
+    out[11] = 0;
+    for (int i = 12; i < 16; i++) out[i] = 0;
     return PT_OK;
 }
 

@@ -673,7 +673,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
     raypk_set(T.R, mk(0, 0, 0), mk(0, 0, -1));
     bool safe = false;
     WaveStats ws = {0, 0, 0, 0};
-    unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0;
+    unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0, t_drained = 0;
     if (COUNT) t_start = __builtin_amdgcn_s_memtime();
 
     for (;;) {
@@ -741,6 +741,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                 if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
             }
             if (drained && idle) { idle = false; dead = true; }
+            if (COUNT && drained && !t_drained) t_drained = __builtin_amdgcn_s_memtime();
         }
         /* (A, continued) one "hit" iteration of trace for old and new paths alike, shader.wgsl:119-127 */
         if (hit) {
@@ -773,8 +774,13 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
         unsigned long long t0 = 0;
         if (COUNT) t0 = __builtin_amdgcn_s_memtime();
         for (;;) {
-            if (!__ballot(trav)) break;
-            if ((uint32_t)__popcll(__ballot(hit)) >= P.refill_min) break;
+            const unsigned long long trav_mask = __ballot(trav);
+            if (!trav_mask) break;
+            const uint32_t n_wait = (uint32_t)__popcll(__ballot(hit));
+            if (n_wait >= P.refill_min) break;
+            /* once the queue is empty the wave never reaches refill_min again: let the waiting lanes go
+             * on as soon as they are as many as the lanes still traversing */
+            if (drained && n_wait >= (uint32_t)__popcll(trav_mask)) break;
 #pragma unroll
             /* Several steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
              * step also runs the triangle code for the lanes that stand at a leaf (they wait for it): measured
@@ -800,6 +806,13 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
             atomicAdd(&P.counters[13], ws.leaf_runs);
             atomicAdd(&P.counters[14], outer_iters);
             atomicAdd(&P.counters[15], shade_lanes);
+            /* the tail: time this wave went on after it found the queue empty (timestamps of
+             * different XCDs are not comparable, so only differences within a wave are kept) */
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            if (!t_drained) t_drained = t_end;
+            atomicMax(&P.counters[16], t_end - t_start);
+            atomicMax(&P.counters[17], t_end - t_drained);
+            atomicAdd(&P.counters[20], t_end - t_drained);
         }
     }
 }

@@ -13,7 +13,7 @@ p = pkg.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=
 with pkg.Renderer(p) as r:
     r.upload_scene(scenes.spheres_for(cfg["spheres"]), tris, bvh)
     r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
-    r.render_frames(0, 1)
+    r.render_frames(0, int(os.environ.get("FRAMES", "1")))
     c, d, t = r.counters(), r.debug_stats(), r.timing()
 print(c); print(d); print(t)
 print("trav share of wave time %.3f" % (d["trav_clocks"] / d["wave_clocks"]))
@@ -21,3 +21,6 @@ print("inner lanes/step %.1f  leaf runs/step %.3f  leaf lanes/run %.1f" % (
     d["inner_lanes"] / d["trav_steps"], d["leaf_runs"] / d["trav_steps"], d["leaf_lanes"] / max(1, d["leaf_runs"])))
 print("outer iters %d  shade lanes/iter %.1f  steps/outer %.1f" % (d["outer_iters"], d["shade_lanes"] / d["outer_iters"], d["trav_steps"] / d["outer_iters"]))
 print("inner visits/cast %.1f (boxes/2=%.1f)" % (d["inner_lanes"] / c["path_kernel_ray_casts"], c["path_kernel_box_tests"] / 2 / c["path_kernel_ray_casts"]))
+print("tail (after a wave found the queue empty): longest %.3f of the longest wave lifetime, summed %.4f of all wave time" % (
+    d["longest_tail"] / d["longest_wave"], d["tail_sum"] / d["wave_clocks"]))
+print("kernel %.3f ms by events; longest wave %d clocks -> %.1f MHz timestamp clock" % (t["path_ms"], d["longest_wave"], d["longest_wave"] / t["path_ms"] / 1e3))

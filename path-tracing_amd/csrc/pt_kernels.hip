@@ -914,9 +914,9 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int
     if (getenv("PT_FORCE_SPILL") && kp.stack_entries > PT_PATH_LDS_STACK) spill = true;
     uint32_t lds_entries = spill ? PT_PATH_LDS_STACK : kp.stack_entries;
     const size_t lds = block_lds_bytes(lds_entries);
-    /* persistent grid: as many 4-wave blocks per CU as stay resident (8 at most) */
+    /* persistent grid: as many 4-wave blocks per CU as stay resident */
     int per_cu = (int)((160 * 1024 - 512) / lds);
-    if (per_cu > 8) per_cu = 8;
+    if (per_cu > PT_PATH_WAVES_PER_EU) per_cu = PT_PATH_WAVES_PER_EU;     /* 4 SIMDs x waves per SIMD / 4 waves per block */
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu);

@@ -3,7 +3,7 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
 
-A "step" is one complete render of the configuration (default: BASELINE config 4,
+A "step" is one complete render of the configuration (default: benchmark configuration 4,
 dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
 max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
 one process per GPU with torch.distributed.run; the image is sharded over ranks in

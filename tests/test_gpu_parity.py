@@ -42,7 +42,7 @@ def test_primary_hits_bit_exact(pkg, scenes, oracle, n, w, h):
 
 
 def test_primary_hits_bit_exact_full_1080p_dragon8k(pkg, scenes, oracle):
-    """BASELINE config 2 at its full resolution (2 M primary rays, legacy depth-21 BVH)."""
+    """Benchmark configuration 2 at its full resolution (2 M primary rays, legacy depth-21 BVH)."""
     cfg, r, op, sc = _setup(pkg, scenes, oracle, 2, rays_per_pixel=1)
     with r:
         ids, dist = r.primary_hits()

@@ -419,9 +419,9 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->d_accum = c->d_accum_own;
     if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
     if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
-    /* sample buffer: as many frames per batch as fit the budget (default 12 GiB, PT_SAMPLE_BUDGET_MB) */
+    /* sample buffer: as many frames per batch as fit the budget (default 64 GiB of the 288 GB, PT_SAMPLE_BUDGET_MB) */
     {
-        size_t budget = (size_t)12 << 30;
+        size_t budget = (size_t)64 << 30;
         if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
         /* hit pixels are stored in interleaved groups of 64; slot numbers are 32-bit */
         size_t slots_per_frame = ((npix + 63) / 64 * 64) * params->rays_per_pixel;

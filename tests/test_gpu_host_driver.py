@@ -121,3 +121,69 @@ def test_pt_render_walk_matches_the_renderer(pkg, oracle_shared, tmp_path):
     assert [np.float32(x) for x in nums[1].split(",")[:3:1][0:2]] == [np.float32(x) for x in rot[:2]]
     want = _srgb8(img)
     assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+def test_two_contexts_interleaved_and_from_two_threads(pkg, scenes, oracle_shared):
+    """Contexts are independent: two of them with different scenes and sizes, driven alternately
+    from one thread and then each from its own thread, give the oracle's images."""
+    import threading
+    setups = []
+    for n, (w, h) in ((1, (96, 54)), (2, (80, 60))):
+        cfg = scenes.config(n, width=w, height=h, rays_per_pixel=2)
+        tris, bvh = scenes.mesh(cfg["mesh"])
+        sp = scenes.spheres_for(cfg["spheres"])
+        kw = dict(width=w, height=h, rays_per_pixel=2, max_bounce_count=cfg["max_bounce_count"])
+        r = pkg.Renderer(pkg.default_params(flags=pkg.PT_FLAG_EXACT_MATH, **kw), device=0)
+        r.upload_scene(sp, tris, bvh)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        op = oracle_shared.default_params(**kw)
+        want = oracle_shared.render_frames(op, oracle_shared.scene(sp, tris, bvh), cfg["camera_position"],
+                                           cfg["camera_rotation"], 0, 4)
+        setups.append((r, want))
+    try:
+        for _ in range(4):                        # alternate: one frame each
+            for r, _w in setups:
+                r.render(1)
+        for r, want in setups:
+            assert np.array_equal(bits(r.read_accum(4)[..., :3]), bits(want[..., :3]))
+
+        def work(r):
+            r.set_camera(r.camera_position, r.camera_rotation)      # restart at frame 0
+            for _ in range(4):
+                r.render(1)
+            r.synchronize()
+        threads = [threading.Thread(target=work, args=(r,)) for r, _w in setups]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for r, want in setups:
+            assert np.array_equal(bits(r.read_accum(4)[..., :3]), bits(want[..., :3]))
+    finally:
+        for r, _w in setups:
+            r.close()
+
+
+def test_create_destroy_does_not_leak_device_memory(pkg, scenes):
+    import torch
+    cfg = scenes.config(1, width=320, height=200, rays_per_pixel=4)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    sp = scenes.spheres_for(cfg["spheres"])
+
+    def cycle():
+        r = pkg.Renderer(pkg.default_params(width=320, height=200, rays_per_pixel=4), device=0)
+        with r:
+            r.upload_scene(sp, tris, bvh)
+            r.upload_scene(sp, tris, bvh)            # re-upload replaces the scene buffers
+            r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+            r.render(2)
+            r.synchronize()
+
+    cycle()
+    torch.cuda.synchronize()
+    free0, _total = torch.cuda.mem_get_info(0)
+    for _ in range(20):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _total = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 64 << 20, "device memory shrank by %d MiB over 20 create/destroy cycles" % ((free0 - free1) >> 20)

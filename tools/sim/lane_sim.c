@@ -133,6 +133,14 @@ int sim_stale(const orc_params *p, const orc_scene *s, const float cam[3], const
     return 0;
 }
 
+/* histogram of bounce casts per path (bin 15 = 15 or more) and of node visits per cast (bins of 16 visits) */
+void sim_histograms(uint64_t casts_per_path[16], uint64_t visits_per_cast[32]) {
+    memset(casts_per_path, 0, 16 * sizeof(uint64_t));
+    memset(visits_per_cast, 0, 32 * sizeof(uint64_t));
+    for (size_t i = 0; i < g_npath; i++) casts_per_path[g_paths[i].n_casts < 15 ? g_paths[i].n_casts : 15]++;
+    for (size_t i = 0; i < g_ncast; i++) { uint32_t b = g_casts[i].n_visits / 16; visits_per_cast[b < 31 ? b : 31]++; }
+}
+
 void sim_sizes(uint64_t out[3]) { out[0] = g_npath; out[1] = g_ncast; out[2] = g_nvis; }
 
 typedef struct {

@@ -98,8 +98,7 @@ class ShardedRenderer:
         import torch
         import torch.distributed as dist
 
-        self.buffer.zero_()
-        torch.cuda.synchronize()
+        self.r.reset_accum()          # zeroes the bound buffer on the library's stream, ordered before the render
 
         def all_reduce():
             self.r.synchronize()                  # kernels run on the library's own stream

@@ -7,16 +7,19 @@
  *
  *   primary_kernel  one lane per pixel, one wave per 8x8 tile.  Every sample of
  *                   a pixel shares the same primary ray (the shader has no
- *                   sub-pixel jitter, shader.wgsl:80-101), so the first cast is
- *                   done once per pixel and frame.  Miss pixels are finished
+ *                   sub-pixel jitter, shader.wgsl:80-101) and the camera is fixed
+ *                   within a call, so the first cast is done once per pixel and
+ *                   batch of frames.  Miss pixels get their constant radiance
  *                   here; hit pixels are appended to a compact list.
- *   path_kernel     persistent waves; each lane owns one path (pixel, sample)
- *                   from its first bounce to termination and refills itself from
- *                   a global queue (wave ballot + one atomic per refill), so
- *                   lanes stay busy although paths have very different lengths.
- *                   BVH traversal stacks live in LDS, one column per lane.
- *   resolve_kernel  per hit pixel: adds the samples in the shader's order and
- *                   applies the progressive accumulation (shader.wgsl:99-106).
+ *   path_kernel     persistent waves, one launch per batch of frames; each lane
+ *                   owns one path (hit pixel, frame, sample) from its first
+ *                   bounce to termination and refills itself from a global queue
+ *                   (wave ballot + one atomic per refill), so lanes stay busy
+ *                   although paths have very different lengths.  BVH traversal is
+ *                   resumable per lane; stacks live in LDS, one column per lane.
+ *   resolve_kernel  per pixel: adds the samples of every frame of the batch in
+ *                   the shader's order and applies the progressive accumulation
+ *                   (shader.wgsl:99-106) frame by frame.
  *
  * All arithmetic that decides a hit is plain IEEE binary32 in the shader's
  * evaluation order with FMA contraction off, so closest-hit ids and distances

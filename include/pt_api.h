@@ -179,7 +179,8 @@ int pt_reset_counters(pt_ctx *ctx);
  * nodes summed over steps, [4] lanes whose leaf code ran, [5] steps in which leaf code ran,
  * [6] outer iterations, [7] lanes shaded summed over outer iterations, [8] longest wave lifetime,
  * [9] longest time a wave went on after it found the queue empty, [10] that time summed over
- * waves, [11..15] reserved.  No reference counterpart. */
+ * waves, [11] ticks of the 100 MHz device clock from the earliest wave start to the first "queue
+ * empty", [12] to the last wave end (one launch), [13..15] reserved.  No reference counterpart. */
 int pt_get_debug_stats(pt_ctx *ctx, uint64_t out[16]);
 int pt_get_timing(pt_ctx *ctx, pt_timing *out);      /* synchronises */
 int pt_reset_timing(pt_ctx *ctx);

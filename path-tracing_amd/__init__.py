@@ -362,7 +362,7 @@ class Renderer:
         out = (C.c_uint64 * 16)()
         self._check(self._L.pt_get_debug_stats(self._ctx, out))
         names = ["wave_clocks", "trav_clocks", "trav_steps", "inner_lanes", "leaf_lanes", "leaf_runs",
-                 "outer_iters", "shade_lanes", "longest_wave", "longest_tail", "tail_sum"]
+                 "outer_iters", "shade_lanes", "longest_wave", "longest_tail", "tail_sum", "first_drained_ticks", "last_end_ticks"]
         return dict(zip(names, [int(x) for x in out]))
 
     def reset_counters(self):

@@ -625,8 +625,12 @@ int pt_get_debug_stats(pt_ctx *c, uint64_t out[16]) {
     out[8] = h[16];                 /* longest wave lifetime */
     out[9] = h[17];                 /* longest time a wave went on after it found the queue empty */
     out[10] = h[20];                /* that time summed over waves */
-    out[11] = 0;
-    for (int i = 12; i < 16; i++) out[i] = 0;
+    {   /* device real-time clock (100 MHz): from the earliest wave start to the first "queue empty" and to the last wave end */
+        const unsigned long long t0 = (1ull << 62) - h[21];
+        out[11] = h[21] ? (1ull << 62) - h[22] - t0 : 0;
+        out[12] = h[21] ? h[23] - t0 : 0;
+    }
+    for (int i = 13; i < 16; i++) out[i] = 0;
     return PT_OK;
 }
 

@@ -677,7 +677,8 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
     bool safe = false;
     WaveStats ws = {0, 0, 0, 0};
     unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0, t_drained = 0;
-    if (COUNT) t_start = __builtin_amdgcn_s_memtime();
+    unsigned long long rt_start = 0, rt_drained = 0;      /* constant-rate device clock (100 MHz), comparable across waves */
+    if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); rt_start = wall_clock64(); }
 
     for (;;) {
         if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(hit)); }
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
                 if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
             }
             if (drained && idle) { idle = false; dead = true; }
-            if (COUNT && drained && !t_drained) t_drained = __builtin_amdgcn_s_memtime();
+            if (COUNT && drained && !t_drained) { t_drained = __builtin_amdgcn_s_memtime(); rt_drained = wall_clock64(); }
         }
         /* (A, continued) one "hit" iteration of trace for old and new paths alike, shader.wgsl:119-127 */
         if (hit) {
@@ -816,6 +817,13 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
             atomicMax(&P.counters[16], t_end - t_start);
             atomicMax(&P.counters[17], t_end - t_drained);
             atomicAdd(&P.counters[20], t_end - t_drained);
+            /* wall-clock timeline of the launch: earliest wave start, earliest "queue empty", latest end
+             * (minima kept as maxima of 2^62 - t) */
+            const unsigned long long rt_end = wall_clock64();
+            if (!rt_drained) rt_drained = rt_end;
+            atomicMax(&P.counters[21], (1ull << 62) - rt_start);
+            atomicMax(&P.counters[22], (1ull << 62) - rt_drained);
+            atomicMax(&P.counters[23], rt_end);
         }
     }
 }

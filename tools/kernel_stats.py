@@ -24,3 +24,5 @@ print("inner visits/cast %.1f (boxes/2=%.1f)" % (d["inner_lanes"] / c["path_kern
 print("tail (after a wave found the queue empty): longest %.3f of the longest wave lifetime, summed %.4f of all wave time" % (
     d["longest_tail"] / d["longest_wave"], d["tail_sum"] / d["wave_clocks"]))
 print("kernel %.3f ms by events; longest wave %d clocks -> %.1f MHz timestamp clock" % (t["path_ms"], d["longest_wave"], d["longest_wave"] / t["path_ms"] / 1e3))
+print("wall clock (100 MHz ticks): first wave sees the queue empty after %.3f ms, last wave ends after %.3f ms (kernel by events %.3f ms): tail %.3f ms" % (
+    d["first_drained_ticks"] / 1e5, d["last_end_ticks"] / 1e5, t["path_ms"], (d["last_end_ticks"] - d["first_drained_ticks"]) / 1e5))

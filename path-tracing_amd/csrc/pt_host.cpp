@@ -332,6 +332,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
         PTKernelParams k;
         fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
         HIP_TRY(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(PTControl), c->stream));
+        if (c->shard_world > 1)     /* pixels of other ranks: marked "not mine" (0xfefefefe), the primary kernel visits owned tiles only */
+            HIP_TRY(c, hipMemsetAsync(c->d_pixel_hit, 0xfe, (size_t)c->params.width * c->params.height * sizeof(uint32_t), c->stream));
         { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream)); t.done(); }
         { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream)); t.done(); }
         { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }

@@ -37,7 +37,7 @@
 #define PT_PI 3.14159f             /* shader.wgsl:36,365 */
 #define PT_NONE INT32_MIN
 #define PT_PIXEL_MISS 0xffffffffu       /* pixel_hit: primary ray hit nothing */
-#define PT_PIXEL_NOT_MINE 0xfffffffeu   /* pixel_hit: pixel belongs to another rank's shard */
+#define PT_PIXEL_NOT_MINE 0xfefefefeu   /* pixel_hit: pixel belongs to another rank's shard (the host fills the array with 0xfe bytes) */
 
 #define PT_WAVES_PER_BLOCK 4
 #define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
@@ -563,14 +563,20 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
     M.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) * P.stack_entries * 256u;
     M.limit = M.base + P.stack_entries * 256u; M.spill = nullptr; M.spill_stride = 0;
-    /* block = 16x16 pixels, wave = 8x8 tile */
-    const uint32_t px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool inside = px < P.width && py < P.height;
-    /* pixel sharding: a wave's 8x8 tile belongs to rank (tile_x + tile_y) % world; the ids/distance
-     * output (AOV) always covers the whole image */
-    const bool mine = AOV || P.shard_world <= 1u || ((px >> 3) + (py >> 3)) % P.shard_world == P.shard_rank;
-    const bool valid = inside && mine;
+    uint32_t px, py;
+    if (AOV || P.shard_world <= 1u) {
+        /* block = 16x16 pixels, wave = 8x8 tile (the ids/distance output always covers the whole image) */
+        px = blockIdx.x * 16u + (wave & 1u) * 8u + (lane & 7u);
+        py = blockIdx.y * 16u + (wave >> 1) * 8u + (lane >> 3);
+    } else {
+        /* pixel sharding: this rank owns the 8x8 tiles with (tile_x + tile_y) % world == rank.  The grid
+         * holds owned tiles only: row of tiles = blockIdx.y, the k-th owned tile of that row per wave. */
+        const uint32_t ty = blockIdx.y, k = blockIdx.x * PT_WAVES_PER_BLOCK + wave;
+        const uint32_t first = (P.shard_rank + P.shard_world - ty % P.shard_world) % P.shard_world;
+        px = (first + k * P.shard_world) * 8u + (lane & 7u);
+        py = ty * 8u + (lane >> 3);
+    }
+    const bool valid = px < P.width && py < P.height;
     Counters cn = {0, 0, 0, 0};
 
     V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
@@ -599,7 +605,6 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
             P.hits[hit_index] = r;
         }
     }
-    if (inside && !mine) P.pixel_hit[pixel] = PT_PIXEL_NOT_MINE;     /* the resolve kernel leaves it alone */
     if (valid) {
         P.pixel_hit[pixel] = hit_index;
         if (!hit) {
@@ -891,6 +896,11 @@ uint32_t pt_spill_entries(uint32_t stack_entries) {
 hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
     if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
     dim3 grid((kp.width + 15) / 16, (kp.height + 15) / 16), block(PT_BLOCK);
+    if (!aov && kp.shard_world > 1u) {        /* owned tiles only: see primary_kernel */
+        const uint32_t tiles_x = (kp.width + 7) / 8, tiles_y = (kp.height + 7) / 8;
+        const uint32_t owned_per_row = (tiles_x + kp.shard_world - 1) / kp.shard_world;
+        grid = dim3((owned_per_row + PT_WAVES_PER_BLOCK - 1) / PT_WAVES_PER_BLOCK, tiles_y);
+    }
     const size_t lds = block_lds_bytes(kp.stack_entries);
     if (aov) {
         hipLaunchKernelGGL((primary_kernel<true, false, true>), grid, block, lds, st, kp);

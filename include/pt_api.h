@@ -190,6 +190,16 @@ int pt_reset_timing(pt_ctx *ctx);
  * nodes and leaves. */
 int pt_scene_info(pt_ctx *ctx, uint32_t *bvh_depth, uint32_t *inner_nodes, uint32_t *leaves);
 
+/* Parity probe: evaluates the small shader functions on the device, one thread per input, so that
+ * they can be compared one by one with a CPU restatement.  out receives 16 floats per input:
+ * [0] random_value(seed) (shader.wgsl:351-358), [1] random_normal (:361-366), [2..4]
+ * random_direction (:369-375), [5..7] random_hemisphere_direction(normal, seed) (:378-382, unused by
+ * the shader itself), [8..10] get_environment_light(dir) (:391-404), [11..13] rotate_vector(dir)
+ * with the camera rotation of pt_set_camera (:327-348), [14..15] zero.  dirs holds n x 3 floats.
+ * Transcendentals follow PT_FLAG_EXACT_MATH of the context.  Needs no scene. */
+int pt_probe_functions(pt_ctx *ctx, const uint32_t *seeds, const float *dirs, const float normal[3],
+                       uint32_t n, float *out);
+
 /* Pixel sharding for multi-GPU renders: after this call the context renders only the 8x8-pixel
  * tiles with (tile_x + tile_y) % world_size == rank and leaves every other pixel of the
  * accumulation buffer untouched.  Each pixel keeps the reference's running mean (shader.wgsl:

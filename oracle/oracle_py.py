@@ -80,6 +80,7 @@ class Oracle:
         L.orc_random_normal.restype = C.c_float
         L.orc_random_normal.argtypes = [C.c_uint32]
         L.orc_random_direction.argtypes = [C.c_uint32, C.POINTER(C.c_float)]
+        L.orc_random_hemisphere_direction.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_float)]
         L.orc_ray_box.restype = C.c_float
         L.orc_bvh_build.restype = C.c_long
         L.orc_bvh_build.argtypes = [C.POINTER(C.c_float), C.c_uint32, C.c_int,
@@ -119,6 +120,11 @@ class Oracle:
     def random_direction(self, seed):
         out = (C.c_float * 3)()
         self.lib.orc_random_direction(C.c_uint32(seed & 0xFFFFFFFF), out)
+        return np.array(out[:], dtype=np.float32)
+
+    def random_hemisphere_direction(self, normal, seed):
+        out = (C.c_float * 3)()
+        self.lib.orc_random_hemisphere_direction(_f3(normal), C.c_uint32(seed & 0xFFFFFFFF), out)
         return np.array(out[:], dtype=np.float32)
 
     def rotate_vector(self, v, angles_deg):

@@ -104,6 +104,14 @@ static orc_v3 random_direction(uint32_t seed) {
     return vnormalize(v3(x, y, z));
 }
 
+/* shader.wgsl:378-382 (never called by the shader).  WGSL sign(): 1, 0 or -1 */
+void orc_random_hemisphere_direction(const float normal[3], uint32_t seed, float out[3]) {
+    orc_v3 dir = random_direction(seed);
+    float d = vdot(from3(normal), dir);
+    float sg = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
+    out[0] = dir.x * sg; out[1] = dir.y * sg; out[2] = dir.z * sg;
+}
+
 void orc_random_direction(uint32_t seed, float out[3]) {
     orc_v3 d = random_direction(seed);
     out[0] = d.x; out[1] = d.y; out[2] = d.z;

@@ -96,6 +96,7 @@ void orc_default_params(orc_params *p);
 float orc_random_value(uint32_t seed);                         /* shader.wgsl:351-358 */
 float orc_random_normal(uint32_t seed);                        /* shader.wgsl:361-366 */
 void  orc_random_direction(uint32_t seed, float out[3]);       /* shader.wgsl:369-375 */
+void  orc_random_hemisphere_direction(const float normal[3], uint32_t seed, float out[3]);   /* shader.wgsl:378-382, dead code in the shader */
 void  orc_rotate_vector(const float v[3], const float angles_deg[3], float out[3]); /* shader.wgsl:327-348 */
 float orc_ray_box(const float origin[3], const float dir[3], const float box[6]);   /* shader.wgsl:237-256 */
 void  orc_ray_triangle(const orc_params *p, const float origin[3], const float dir[3],

@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
-    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard",
+    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -110,6 +110,7 @@ def load_library():
     L.pt_render_frames_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.pt_scale_accum.argtypes = [C.c_void_p, C.c_float]
     L.pt_set_pixel_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pt_probe_functions.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), fp, fp, C.c_uint32, fp]
     L.pt_read_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
     L.pt_reset_accum.argtypes = [C.c_void_p]
     L.pt_bind_accum.argtypes = [C.c_void_p, C.c_void_p]
@@ -322,6 +323,18 @@ class Renderer:
 
     def render_frames_sum(self, first_frame_count, n_frames, frame_stride=1):
         self._check(self._L.pt_render_frames_sum(self._ctx, int(first_frame_count), int(n_frames), int(frame_stride)))
+
+    def probe_functions(self, seeds, dirs, normal):
+        """Device values of the small shader functions for each (seed, dir): dict of arrays."""
+        seeds = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint32))
+        dirs = np.ascontiguousarray(np.asarray(dirs, dtype=np.float32).reshape(-1, 3))
+        assert len(seeds) == len(dirs)
+        out = np.zeros((len(seeds), 16), np.float32)
+        self._check(self._L.pt_probe_functions(self._ctx, seeds.ctypes.data_as(C.POINTER(C.c_uint32)), _fp(dirs),
+                                               _f3(normal), len(seeds), _fp(out)))
+        return {"random_value": out[:, 0], "random_normal": out[:, 1], "random_direction": out[:, 2:5],
+                "random_hemisphere_direction": out[:, 5:8], "environment_light": out[:, 8:11],
+                "rotate_vector": out[:, 11:14]}
 
     def set_pixel_shard(self, rank, world_size):
         """Render only the 8x8 tiles with (tile_x + tile_y) % world_size == rank (multi-GPU)."""

@@ -595,6 +595,31 @@ int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
     return PT_OK;
 }
 
+int pt_probe_functions(pt_ctx *c, const uint32_t *seeds, const float *dirs, const float normal[3], uint32_t n, float *out) {
+    if (!c) return PT_EINVAL;
+    if (!seeds || !dirs || !normal || !out) return fail(c, PT_EINVAL, "argument is NULL");
+    if (n == 0) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    uint32_t *d_seeds = nullptr; float *d_dirs = nullptr, *d_out = nullptr;
+    int rc = PT_OK;
+    hipError_t e;
+    if ((e = hipMalloc(&d_seeds, (size_t)n * 4)) != hipSuccess || (e = hipMalloc(&d_dirs, (size_t)n * 12)) != hipSuccess ||
+        (e = hipMalloc(&d_out, (size_t)n * 64)) != hipSuccess ||
+        (e = hipMemcpy(d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(d_dirs, dirs, (size_t)n * 12, hipMemcpyHostToDevice)) != hipSuccess) {
+        rc = fail(c, PT_EHIP, hipGetErrorString(e));
+    } else {
+        PTKernelParams k;
+        fill_kernel_params(c, 0, 1, 1, 0, k);
+        if ((e = pt_launch_probe(k, (c->params.flags & PT_FLAG_EXACT_MATH) != 0, d_seeds, d_dirs, normal, n, d_out, c->stream)) != hipSuccess ||
+            (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
+            (e = hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost)) != hipSuccess)
+            rc = fail(c, PT_EHIP, hipGetErrorString(e));
+    }
+    dev_free(d_seeds); dev_free(d_dirs); dev_free(d_out);
+    return rc;
+}
+
 int pt_synchronize(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -110,6 +110,8 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact_math,
                            bool count_work, int num_cus, hipStream_t stream);
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t stream);
 hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t stream);
+hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t *seeds, const float *dirs,
+                           const float normal[3], uint32_t n, float *out, hipStream_t stream);
 int pt_max_stack_entries(void);
 uint32_t pt_lane_stride(int num_cus);   /* upper bound of the path kernel's grid size in lanes */
 uint32_t pt_spill_entries(uint32_t stack_entries);

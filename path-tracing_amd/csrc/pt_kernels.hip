@@ -100,6 +100,15 @@ template <bool EXACT> __device__ __forceinline__ V3 random_direction(uint32_t se
 }
 
 /* ---- camera, shader.wgsl:80-95 and 327-348 (trig values come from the host) ---- */
+/* random_hemisphere_direction, shader.wgsl:378-382: dead code in the shader, reachable here through
+ * the function probe only.  WGSL sign(): 1, 0 or -1. */
+template <bool EXACT> __device__ __forceinline__ V3 random_hemisphere_direction(V3 normal, uint32_t seed) {
+    V3 dir = random_direction<EXACT>(seed);
+    float d = dot3(normal, dir);
+    float sg = (d > 0.0f) ? 1.0f : ((d < 0.0f) ? -1.0f : 0.0f);
+    return dir * sg;
+}
+
 __device__ __forceinline__ V3 rotate_vector(const PTKernelParams &P, V3 r) {
     float x = r.x, y = r.y, z = r.z;
     float cos_a = P.cos_a, sin_a = P.sin_a, cos_b = P.cos_b, sin_b = P.sin_b, cos_c = P.cos_c, sin_c = P.sin_c;
@@ -874,6 +883,41 @@ __global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, f
     if (i >= n) return;
     float4 v = accum[i];
     accum[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w);
+}
+
+/* ======================= function probe ======================= */
+/* Evaluates the small shader functions on the device for given inputs, so that tests can compare
+ * them one by one with the CPU restatement.  out[i] = 16 floats: [0] random_value(seed_i),
+ * [1] random_normal, [2..4] random_direction, [5..7] random_hemisphere_direction(normal, seed_i),
+ * [8..10] get_environment_light(dir_i), [11..13] rotate_vector(dir_i) with the context's camera
+ * rotation, [14..15] zero. */
+template <bool EXACT>
+__global__ __launch_bounds__(256) void probe_kernel(PTKernelParams P, const uint32_t *seeds, const float *dirs,
+                                                    float nx, float ny, float nz, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t seed = seeds[i];
+    const V3 dir = ld3(dirs + 3 * i);
+    float *o = out + 16 * (size_t)i;
+    o[0] = random_value(seed);
+    o[1] = random_normal<EXACT>(seed);
+    V3 rd = random_direction<EXACT>(seed);
+    o[2] = rd.x; o[3] = rd.y; o[4] = rd.z;
+    V3 rh = random_hemisphere_direction<EXACT>(mk(nx, ny, nz), seed);
+    o[5] = rh.x; o[6] = rh.y; o[7] = rh.z;
+    V3 e = environment_light<EXACT>(P, dir);
+    o[8] = e.x; o[9] = e.y; o[10] = e.z;
+    V3 rv = rotate_vector(P, dir);
+    o[11] = rv.x; o[12] = rv.y; o[13] = rv.z;
+    o[14] = 0.0f; o[15] = 0.0f;
+}
+
+hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t *seeds, const float *dirs,
+                           const float normal[3], uint32_t n, float *out, hipStream_t st) {
+    dim3 grid((n + 255) / 256), block(256);
+    if (exact) hipLaunchKernelGGL(probe_kernel<true>, grid, block, 0, st, kp, seeds, dirs, normal[0], normal[1], normal[2], n, out);
+    else       hipLaunchKernelGGL(probe_kernel<false>, grid, block, 0, st, kp, seeds, dirs, normal[0], normal[1], normal[2], n, out);
+    return hipGetLastError();
 }
 
 /* ======================= launchers ======================= */

@@ -237,3 +237,21 @@ def test_environment_light(oracle):
     assert oracle.environment_light(p, s.astype(F))[0] > 2.9
     below = np.array([0.0, -0.005, -1.0])
     assert oracle.environment_light(p, below.astype(F)).max() < 1.01   # ground_to_sky_t < 1: no sun term
+
+
+def test_random_hemisphere_direction_is_the_direction_flipped_into_the_hemisphere(oracle):
+    """shader.wgsl:378-382 (dead code in the shader): dir * sign(dot(normal, dir))."""
+    for seed in (1, 2, 77, 123456789, 0xFFFFFFFF):
+        d = oracle.random_direction(seed)
+        for normal in ((0.0, 1.0, 0.0), (0.3, -0.2, 0.9), (-1.0, 0.0, 0.0)):
+            h = oracle.random_hemisphere_direction(normal, seed)
+            dot = np.float32(normal[0]) * d[0] + np.float32(normal[1]) * d[1] + np.float32(normal[2]) * d[2]
+            want = d if dot > 0 else (-d if dot < 0 else d * 0)
+            assert np.array_equal(h, want)
+            assert float(np.dot(np.asarray(normal, np.float32), h)) >= 0.0
+    # a direction perpendicular to the normal is multiplied by sign(0) = 0
+    d = oracle.random_direction(5)
+    n = np.cross(d, np.asarray([1, 0, 0], np.float32)).astype(np.float32)
+    n64 = np.cross(d.astype(np.float64), [1.0, 0.0, 0.0])
+    if np.float32(n[0]) * d[0] + np.float32(n[1]) * d[1] + np.float32(n[2]) * d[2] == 0:
+        assert np.array_equal(oracle.random_hemisphere_direction(n, 5), d * 0) and n64 is not None

@@ -200,6 +200,15 @@ int pt_scene_info(pt_ctx *ctx, uint32_t *bvh_depth, uint32_t *inner_nodes, uint3
 int pt_probe_functions(pt_ctx *ctx, const uint32_t *seeds, const float *dirs, const float normal[3],
                        uint32_t n, float *out);
 
+/* Parity probe for the intersection functions, one thread per input: rays n x 6 (origin, dir), boxes
+ * n x 6 (min, max), triangles n x 9, spheres n x 4 (centre, radius).  out receives 8 floats per
+ * input: [0] ray_box (shader.wgsl:237-256) with the plain divider, [1] the same through the
+ * reciprocal form the traversal uses when its predicates hold (NaN when they do not), [2] did_hit
+ * and [3] distance of ray_triangle (:258-290), [4] did_hit and [5] distance of ray_sphere
+ * (:292-325), distances meaningful where did_hit is set, [6..7] zero.  Needs no scene. */
+int pt_probe_intersections(pt_ctx *ctx, const float *rays, const float *boxes, const float *triangles,
+                           const float *spheres, uint32_t n, float *out);
+
 /* Pixel sharding for multi-GPU renders: after this call the context renders only the 8x8-pixel
  * tiles with (tile_x + tile_y) % world_size == rank and leaves every other pixel of the
  * accumulation buffer untouched.  Each pixel keeps the reference's running mean (shader.wgsl:

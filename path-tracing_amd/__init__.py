@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
-    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions",
+    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -110,6 +110,7 @@ def load_library():
     L.pt_render_frames_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     L.pt_scale_accum.argtypes = [C.c_void_p, C.c_float]
     L.pt_set_pixel_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pt_probe_intersections.argtypes = [C.c_void_p, fp, fp, fp, fp, C.c_uint32, fp]
     L.pt_probe_functions.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), fp, fp, C.c_uint32, fp]
     L.pt_read_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
     L.pt_reset_accum.argtypes = [C.c_void_p]
@@ -335,6 +336,17 @@ class Renderer:
         return {"random_value": out[:, 0], "random_normal": out[:, 1], "random_direction": out[:, 2:5],
                 "random_hemisphere_direction": out[:, 5:8], "environment_light": out[:, 8:11],
                 "rotate_vector": out[:, 11:14]}
+
+    def probe_intersections(self, rays, boxes, triangles, spheres):
+        """Device values of ray_box (plain and reciprocal division), ray_triangle and ray_sphere."""
+        a = [np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1, w))
+             for x, w in ((rays, 6), (boxes, 6), (triangles, 9), (spheres, 4))]
+        n = len(a[0])
+        assert all(len(x) == n for x in a)
+        out = np.zeros((n, 8), np.float32)
+        self._check(self._L.pt_probe_intersections(self._ctx, _fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(a[3]), n, _fp(out)))
+        return {"box": out[:, 0], "box_reciprocal": out[:, 1], "tri_hit": out[:, 2] != 0, "tri_distance": out[:, 3],
+                "sphere_hit": out[:, 4] != 0, "sphere_distance": out[:, 5]}
 
     def set_pixel_shard(self, rank, world_size):
         """Render only the 8x8 tiles with (tile_x + tile_y) % world_size == rank (multi-GPU)."""

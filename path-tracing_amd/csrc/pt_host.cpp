@@ -620,6 +620,27 @@ int pt_probe_functions(pt_ctx *c, const uint32_t *seeds, const float *dirs, cons
     return rc;
 }
 
+int pt_probe_intersections(pt_ctx *c, const float *rays, const float *boxes, const float *triangles, const float *spheres,
+                           uint32_t n, float *out) {
+    if (!c) return PT_EINVAL;
+    if (!rays || !boxes || !triangles || !spheres || !out) return fail(c, PT_EINVAL, "argument is NULL");
+    if (n == 0) return PT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t sizes[5] = {(size_t)n * 24, (size_t)n * 24, (size_t)n * 36, (size_t)n * 16, (size_t)n * 32};
+    const float *src[4] = {rays, boxes, triangles, spheres};
+    float *d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = PT_OK;
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipMalloc(&d[k], sizes[k]);
+    for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipMemcpy(d[k], src[k], sizes[k], hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = pt_launch_probe_intersections(d[0], d[1], d[2], d[3], n, d[4], c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d[4], sizes[4], hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = fail(c, PT_EHIP, hipGetErrorString(e));
+    for (int k = 0; k < 5; k++) dev_free(d[k]);
+    return rc;
+}
+
 int pt_synchronize(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

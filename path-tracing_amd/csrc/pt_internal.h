@@ -110,6 +110,8 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact_math,
                            bool count_work, int num_cus, hipStream_t stream);
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t stream);
 hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t stream);
+hipError_t pt_launch_probe_intersections(const float *rays, const float *boxes, const float *tris, const float *spheres,
+                                         uint32_t n, float *out, hipStream_t stream);
 hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t *seeds, const float *dirs,
                            const float normal[3], uint32_t n, float *out, hipStream_t stream);
 int pt_max_stack_entries(void);

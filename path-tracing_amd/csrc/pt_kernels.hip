@@ -912,6 +912,52 @@ __global__ __launch_bounds__(256) void probe_kernel(PTKernelParams P, const uint
     o[14] = 0.0f; o[15] = 0.0f;
 }
 
+/* Intersection functions for given inputs, one thread per input: ray (origin, dir), box (min, max),
+ * triangle (a, b, c), sphere (centre, radius).  out[i] = 8 floats: [0] ray_box with the plain
+ * divider, [1] ray_box with the reciprocal form (NaN when ray or box fail its predicates),
+ * [2] ray_triangle did_hit (0/1), [3] its distance, [4] ray_sphere did_hit, [5] its distance
+ * (distances are meaningful where did_hit is set), [6..7] zero. */
+__global__ __launch_bounds__(256) void probe_intersections_kernel(const float *rays, const float *boxes, const float *tris,
+                                                                  const float *spheres, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const V3 o = ld3(rays + 6 * i), d = ld3(rays + 6 * i + 3);
+    const float *b = boxes + 6 * i;
+    float *r = out + 8 * (size_t)i;
+    RayPk R;
+    raypk_set(R, o, d);
+    const float4 q0 = make_float4(b[0], b[1], b[3], b[4]), q2 = make_float4(b[2], b[5], b[2], b[5]);
+    float da, db;
+    ray_box2<false>(R, q0, q0, q2, da, db);
+    r[0] = da;
+    bool tame = ray_div_safe(o, d);
+    for (int k = 0; k < 6; k++) tame = tame && pt_div_tame_coordinate(b[k]);
+    float fa = __builtin_nanf(""), fb;
+    if (tame) ray_box2<true>(R, q0, q0, q2, fa, fb);
+    r[1] = fa;
+    /* the triangle record as the host builds it (build_tri_records): same f32 operations */
+    const float *t = tris + 9 * i;
+    PTTriRecord rec;
+    const float abx = t[3] - t[0], aby = t[4] - t[1], abz = t[5] - t[2];
+    const float acx = t[6] - t[0], acy = t[7] - t[1], acz = t[8] - t[2];
+    rec.q[0] = make_float4(t[0], t[1], t[2], abx);
+    rec.q[1] = make_float4(aby, abz, acx, acy);
+    rec.q[2] = make_float4(acz, aby * acz - abz * acy, abz * acx - abx * acz, abx * acy - aby * acx);
+    float dst = 0.0f;
+    const bool th = ray_triangle(o, d, &rec, dst);
+    r[2] = th ? 1.0f : 0.0f; r[3] = dst;
+    float sd = 0.0f;
+    const bool sh = ray_sphere(o, d, spheres + 4 * i, sd);
+    r[4] = sh ? 1.0f : 0.0f; r[5] = sd;
+    r[6] = 0.0f; r[7] = 0.0f;
+}
+
+hipError_t pt_launch_probe_intersections(const float *rays, const float *boxes, const float *tris, const float *spheres,
+                                         uint32_t n, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(probe_intersections_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rays, boxes, tris, spheres, n, out);
+    return hipGetLastError();
+}
+
 hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t *seeds, const float *dirs,
                            const float normal[3], uint32_t n, float *out, hipStream_t st) {
     dim3 grid((n + 255) / 256), block(256);

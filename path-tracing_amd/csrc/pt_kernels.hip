@@ -135,6 +135,8 @@ __device__ __forceinline__ void primary_ray(const PTKernelParams &P, uint32_t px
  * precomputed per ray (same bits).  The caller picks FAST only for rays and
  * scenes that satisfy the predicates in pt_exact_div.h. */
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
 
 template <bool FAST>
@@ -316,9 +318,18 @@ __device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
 
 template <bool FAST, bool COUNT, bool SPILL>
 __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, Trav &T, Counters &cn) {
-    const PTInnerRecord *rec = P.inner + T.cur;
-    float4 q0 = rec->q[0], q1 = rec->q[1], q2 = rec->q[2];
-    const uint2 refs = *reinterpret_cast<const uint2 *>(&rec->q[3]);        /* only 8 of the last 16 bytes are used */
+    /* buffer loads: scalar base + 32-bit offset (no 64-bit address arithmetic per lane), and a record index
+     * outside the array reads zeros instead of faulting */
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.inner, 0, (int)P.inner_bytes, 0x00020000);
+    const uint32_t off = T.cur * 64u;
+    const u4_t w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    const u4_t w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
+    const u4_t w2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+    const u2_t w3 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 48u, 0, 0);
+    float4 q0 = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+    float4 q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
+    float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
+    const uint2 refs = make_uint2(w3.x, w3.y);
     float dst_a, dst_b;
     ray_box2<FAST>(T.R, q0, q1, q2, dst_a, dst_b);
 #ifdef PT_ABL_DIV2      /* sensitivity probe: a second box test whose result cannot change anything */

@@ -282,7 +282,8 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.leaf_min = c->leaf_min;
     k.leaf_shift = c->leaf_shift;
     k.xcd_queues = getenv("PT_NO_XCD_QUEUES") ? 0u : 1u;
-    k.inner = c->d_inner; k.inner_bytes = (c->inner_count ? c->inner_count : 1u) * (uint32_t)sizeof(PTInnerRecord); k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
+    k.inner = c->d_inner; k.inner_bytes = (c->inner_count ? c->inner_count : 1u) * (uint32_t)sizeof(PTInnerRecord);
+    k.tris_bytes = (c->tri_count ? c->tri_count : 1u) * (uint32_t)sizeof(PTTriRecord); k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
     k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
     k.pixel_hit = c->d_pixel_hit; k.pixel_const = c->d_pixel_const;
     k.spill = c->d_spill; k.spill_stride = pt_lane_stride(c->num_cus);

@@ -87,6 +87,7 @@ struct PTKernelParams {
     uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
     uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;
+    uint32_t tris_bytes;           /* size of the triangle-record array (at most 2^24 x 48 bytes) */
     uint32_t inner_bytes;          /* size of the inner-record array (below 2^32: at most 2^24 triangles) */
     const PTTriRecord *tris;
     const float *spheres;

@@ -189,8 +189,12 @@ __device__ __forceinline__ bool ray_div_safe(V3 o, V3 d) {
 #define PT_KEEP_LOADS_TOGETHER(a, b, c) asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x))
 
 /* ---- ray_triangle distance part, shader.wgsl:258-280 (edges and normal precomputed) ---- */
+__device__ __forceinline__ bool ray_triangle_q(V3 o, V3 d, float4 q0, float4 q1, float4 q2, float &dst_out);
 __device__ __forceinline__ bool ray_triangle(V3 o, V3 d, const PTTriRecord *t, float &dst_out) {
     float4 q0 = t->q[0], q1 = t->q[1], q2 = t->q[2];
+    return ray_triangle_q(o, d, q0, q1, q2, dst_out);
+}
+__device__ __forceinline__ bool ray_triangle_q(V3 o, V3 d, float4 q0, float4 q1, float4 q2, float &dst_out) {
     PT_KEEP_LOADS_TOGETHER(q0, q1, q2);
     V3 a = mk(q0.x, q0.y, q0.z), edge_ab = mk(q0.w, q1.x, q1.y), edge_ac = mk(q1.z, q1.w, q2.x);
     V3 normal_vector = mk(q2.y, q2.z, q2.w);
@@ -374,7 +378,13 @@ __device__ __forceinline__ void leaf_visit(const PTKernelParams &P, Trav &T, Cou
     if (cnt == PT_REF_COUNT_ESCAPE) cnt = P.big_leaf_count[first];
     for (uint32_t i = first; i < first + cnt; i++) {
         float dst;
-        bool hit = ray_triangle(o, d, P.tris + i, dst);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.tris, 0, (int)P.tris_bytes, 0x00020000);
+        const u4_t w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 48u, 0, 0);
+        const u4_t w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 48u + 16u, 0, 0);
+        const u4_t w2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, i * 48u + 32u, 0, 0);
+        bool hit = ray_triangle_q(o, d, make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w)),
+                                  make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w)),
+                                  make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w)), dst);
         if (COUNT) cn.tris++;
         if (hit && dst < T.best_t) { T.best_t = dst; T.best_id = (int32_t)i; }
     }
@@ -662,7 +672,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_PATH_WAVES_PER_EU 6
 #endif
 #ifndef PT_STEPS_PER_CHECK
-#define PT_STEPS_PER_CHECK 6
+#define PT_STEPS_PER_CHECK 9
 #endif
 #ifndef PT_LEAF_PERIOD
 #define PT_LEAF_PERIOD 3
@@ -811,7 +821,7 @@ __global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKern
              * on as soon as they are as many as the lanes still traversing */
             if (drained && n_wait >= (uint32_t)__popcll(trav_mask)) break;
 #pragma unroll
-            /* Several steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
+            /* Several (nine) steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
              * step also runs the triangle code for the lanes that stand at a leaf (they wait for it): measured
              * faster than deciding from lane counts in every step (2.98 -> 2.90 ms per frame). */
             for (int rep = 0; rep < PT_STEPS_PER_CHECK; rep++) {

@@ -152,6 +152,13 @@ int pt_scale_accum(pt_ctx *ctx, float s);
  * pixel stride).  Synchronises the stream first. */
 int pt_read_accum(pt_ctx *ctx, float *out, uint32_t stride_floats);
 
+/* Writes the accumulation buffer from host memory (same layouts as pt_read_accum).  The buffer and
+ * the frame count ARE the resumable state of a progressive render (src/main.rs:365-379, 448-452):
+ * save the image and the number of frames in it, later write it back and continue with
+ * pt_render_frames(ctx, frames_done, n).  No reference counterpart (the reference keeps the
+ * state on the GPU only).  Synchronises the stream first. */
+int pt_write_accum(pt_ctx *ctx, const float *in, uint32_t stride_floats);
+
 /* Zero-fills the accumulation buffer (its initial state, main.rs:365-379). */
 int pt_reset_accum(pt_ctx *ctx);
 

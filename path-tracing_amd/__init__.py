@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
-    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections",
+    "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -113,6 +113,7 @@ def load_library():
     L.pt_probe_intersections.argtypes = [C.c_void_p, fp, fp, fp, fp, C.c_uint32, fp]
     L.pt_probe_functions.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), fp, fp, C.c_uint32, fp]
     L.pt_read_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
+    L.pt_write_accum.argtypes = [C.c_void_p, fp, C.c_uint32]
     L.pt_reset_accum.argtypes = [C.c_void_p]
     L.pt_bind_accum.argtypes = [C.c_void_p, C.c_void_p]
     L.pt_accum_device_ptr.argtypes = [C.c_void_p]
@@ -362,6 +363,16 @@ class Renderer:
         out = np.empty((self.height, self.width, stride_floats), dtype=np.float32)
         self._check(self._L.pt_read_accum(self._ctx, _fp(out), stride_floats))
         return out
+
+    def write_accum(self, image, frames_done=None):
+        """Restores a saved accumulation buffer ((H, W, 3) or (H, W, 4) float32); with frames_done
+        the next render() continues the running mean from there."""
+        a = np.ascontiguousarray(np.asarray(image, dtype=np.float32))
+        if a.shape[:2] != (self.height, self.width) or a.shape[2] not in (3, 4):
+            raise ValueError("image must be (height, width, 3 or 4)")
+        self._check(self._L.pt_write_accum(self._ctx, _fp(a), a.shape[2]))
+        if frames_done is not None:
+            self.frame_count = int(frames_done)
 
     def bind_accum(self, device_ptr):
         self._check(self._L.pt_bind_accum(self._ctx, C.c_void_p(device_ptr)))

@@ -555,6 +555,22 @@ int pt_read_accum(pt_ctx *c, float *out, uint32_t stride_floats) {
     return PT_OK;
 }
 
+int pt_write_accum(pt_ctx *c, const float *in, uint32_t stride_floats) {
+    if (!c) return PT_EINVAL;
+    if (!in || (stride_floats != 3 && stride_floats != 4)) return fail(c, PT_EINVAL, "in is NULL or stride_floats is not 3 or 4");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stride_floats == 4) {
+        HIP_TRY(c, hipMemcpy(c->d_accum, in, npix * sizeof(float4), hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(npix * 4, 0.0f);
+        for (size_t i = 0; i < npix; i++) { tmp[4 * i] = in[3 * i]; tmp[4 * i + 1] = in[3 * i + 1]; tmp[4 * i + 2] = in[3 * i + 2]; }
+        HIP_TRY(c, hipMemcpy(c->d_accum, tmp.data(), npix * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    return PT_OK;
+}
+
 int pt_reset_accum(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));

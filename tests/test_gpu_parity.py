@@ -367,3 +367,28 @@ def test_pixel_shards_add_up_to_the_unsharded_image(pkg, scenes, oracle_shared, 
     assert np.array_equal(bits(whole[..., :3]), bits(oimg[..., :3]))
     for k in counts:
         assert counts[k] == cw[k], k
+
+
+def test_checkpoint_and_resume_through_host_memory(pkg, scenes, oracle_shared, tmp_path):
+    """The accumulation buffer plus the frame count are the whole state of a progressive render:
+    saved after 3 frames, restored into a NEW context (both pixel strides), continued for 2 more
+    frames, it equals 5 frames rendered in one go, bit for bit."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH, width=96, height=54, rays_per_pixel=2)
+    with r:
+        r.render(3)
+        np.save(tmp_path / "ckpt.npy", r.read_accum(3))
+        frames_done = r.frame_count
+    want = oracle_shared.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, 5)
+    for stride in (3, 4):
+        cfg2, r2, _op, _sc = _setup(pkg, scenes, oracle_shared, 1, flags=pkg.PT_FLAG_EXACT_MATH, width=96, height=54, rays_per_pixel=2)
+        with r2:
+            img = np.load(tmp_path / "ckpt.npy")
+            if stride == 4:
+                img = np.concatenate([img, np.zeros(img.shape[:2] + (1,), np.float32)], axis=2)
+            r2.write_accum(img, frames_done)
+            r2.render(2)
+            assert r2.frame_count == 5
+            got = r2.read_accum(4)
+            with pytest.raises(ValueError):
+                r2.write_accum(np.zeros((5, 5, 3), np.float32))
+        assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))

@@ -126,3 +126,30 @@ def test_formatter_output_feeds_the_builder():
     out_tr, nodes = pt.bvh_build(tris.reshape(-1, 9), 8)
     assert nodes.shape[1] == 9 and out_tr.shape == (tris.size // 9, 9)
     assert sorted(map(tuple, out_tr.tolist())) == sorted(map(tuple, tris.reshape(-1, 9).tolist()))
+
+
+def test_pt_prepare_tool_runs_both_preparation_steps(tmp_path):
+    """pt_prepare = data_formatter.js followed by prepare_data/src/main.rs: its files equal what the
+    library calls give, and its --bin mode (step 2 only) reproduces the reference's teapot pair from
+    the triangle file the reference's formatter wrote."""
+    import subprocess
+    pt = load_package()
+    tool = os.path.join(ROOT, "path-tracing_amd", "pt_prepare")
+    assert os.path.exists(tool), "build pt_prepare with make -C path-tracing_amd"
+    b, v = str(tmp_path / "m.bin"), str(tmp_path / "m_bvh.bin")
+    res = subprocess.run([tool, os.path.join(OBJ, "small_teapot.stl"), b, v, "--scale", "0.5", "--max-depth", "9"],
+                         capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    tris = pt.stl_format(open(os.path.join(OBJ, "small_teapot.stl"), "rb").read(), 0.5)
+    out_tr, nodes = pt.bvh_build(tris.reshape(-1, 9), 9)
+    assert open(b, "rb").read() == out_tr.tobytes() and open(v, "rb").read() == nodes.tobytes()
+    # step 2 alone (the Rust tool's job), default depth limit
+    import shutil
+    shutil.copy(os.path.join(OBJ, "teapot.bin"), tmp_path / "t.bin")
+    res = subprocess.run([tool, "--bin", str(tmp_path / "t.bin"), str(tmp_path / "t_bvh.bin")],       # default depth 16
+                         capture_output=True, text=True, timeout=60)
+    assert res.returncode == 0, res.stderr
+    t2, n2 = pt.bvh_build(np.fromfile(os.path.join(OBJ, "teapot.bin"), "<f4").reshape(-1, 9), 16)
+    assert open(tmp_path / "t.bin", "rb").read() == t2.tobytes() and open(tmp_path / "t_bvh.bin", "rb").read() == n2.tobytes()
+    assert subprocess.run([tool, "nope.stl", b, v], capture_output=True).returncode == 1
+    assert subprocess.run([tool, "only_one_argument"], capture_output=True).returncode == 2

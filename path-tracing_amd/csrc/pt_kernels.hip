@@ -41,6 +41,10 @@
 
 #define PT_WAVES_PER_BLOCK 4
 #define PT_BLOCK (64 * PT_WAVES_PER_BLOCK)
+#ifndef PT_PATH_WAVES_PER_BLOCK
+#define PT_PATH_WAVES_PER_BLOCK 4            /* the path kernel uses no block-level communication: any size works */
+#endif
+#define PT_PATH_BLOCK (64 * PT_PATH_WAVES_PER_BLOCK)
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -679,12 +683,12 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
 template <bool EXACT, bool COUNT, bool SPILL>
-__global__ __launch_bounds__(PT_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
+__global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
     M.base = wave * lds_entries * 256u;
     M.limit = M.base + lds_entries * 256u;
-    M.spill = SPILL ? P.spill + (blockIdx.x * PT_BLOCK + threadIdx.x) : nullptr;
+    M.spill = SPILL ? P.spill + (blockIdx.x * PT_PATH_BLOCK + threadIdx.x) : nullptr;
     M.spill_stride = P.spill_stride;
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
@@ -990,7 +994,7 @@ hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t 
 /* ======================= launchers ======================= */
 int pt_max_stack_entries(void) { return 64; }       /* 64 entries x 4 waves x 256 B = 64 KiB, the default dynamic-LDS limit */
 /* the persistent grid never exceeds 8 blocks per CU */
-uint32_t pt_lane_stride(int num_cus) { return (uint32_t)num_cus * 8u * PT_BLOCK; }
+uint32_t pt_lane_stride(int num_cus) { return (uint32_t)num_cus * 32u * 64u; }      /* at most 32 waves per CU */
 
 #define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS when it spills */
 #define PT_PATH_LDS_ALL 30        /* deepest tree whose whole stack the path kernel keeps in LDS */
@@ -1028,7 +1032,7 @@ hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, b
 template <bool SPILL>
 static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool count, dim3 grid, size_t lds, uint32_t lds_entries,
                                  hipStream_t st) {
-    dim3 block(PT_BLOCK);
+    dim3 block(PT_PATH_BLOCK);
     if (count) {
         if (exact) hipLaunchKernelGGL((path_kernel<true, true, SPILL>), grid, block, lds, st, kp, lds_entries);
         else       hipLaunchKernelGGL((path_kernel<false, true, SPILL>), grid, block, lds, st, kp, lds_entries);
@@ -1045,10 +1049,11 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int
     bool spill = kp.stack_entries > PT_PATH_LDS_ALL;
     if (getenv("PT_FORCE_SPILL") && kp.stack_entries > PT_PATH_LDS_STACK) spill = true;
     uint32_t lds_entries = spill ? PT_PATH_LDS_STACK : kp.stack_entries;
-    const size_t lds = block_lds_bytes(lds_entries);
-    /* persistent grid: as many 4-wave blocks per CU as stay resident */
+    const size_t lds = block_lds_bytes(lds_entries) / PT_WAVES_PER_BLOCK * PT_PATH_WAVES_PER_BLOCK;
+    /* persistent grid: as many blocks per CU as stay resident */
     int per_cu = (int)((160 * 1024 - 512) / lds);
-    if (per_cu > PT_PATH_WAVES_PER_EU) per_cu = PT_PATH_WAVES_PER_EU;     /* 4 SIMDs x waves per SIMD / 4 waves per block */
+    const int by_registers = PT_PATH_WAVES_PER_EU * 4 / PT_PATH_WAVES_PER_BLOCK;     /* 4 SIMDs x waves per SIMD / waves per block */
+    if (per_cu > by_registers) per_cu = by_registers;
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu);

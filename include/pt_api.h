@@ -135,6 +135,22 @@ int pt_set_camera(pt_ctx *ctx, const float position[3], const float rotation_deg
  * frame_count 0 overwrites the buffer.  Asynchronous on the context's stream. */
 int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames);
 
+/* pt_render_frames for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same
+ * result as pt_render_frames, bit for bit, but the per-batch working state (hit list, control words,
+ * per-pixel tables, sample buffer) lives in a static device array of pt_static_scratch_bytes()
+ * (64 MiB) that every GPU the library runs on holds until the process ends, and the call itself
+ * calls no hipMalloc / hipFree / hipEventCreate: it only enqueues memsets and kernels on the
+ * context's stream.  Scene, camera and accumulation buffer are the context's, as in
+ * pt_render_frames.  Needs 256 + 36 * width * height + 16 * roundup64(width * height) *
+ * rays_per_pixel bytes for a one-frame batch (more frames per batch are used when they fit);
+ * PT_EINVAL with the two byte counts in the message when that exceeds the array.  The kernels are not
+ * timed (pt_get_timing does not see them).  All contexts of one GPU share that GPU's array: calls
+ * that overlap in time on one GPU (different contexts or threads) race; run them one after the
+ * other (pt_synchronize between contexts). */
+int pt_render_frames_static(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames);
+size_t pt_static_scratch_bytes(void);
+
 /* Frame-sharded form for multi-GPU renders: ADDS the per-pixel mean of frames
  * first_frame_count, +frame_stride, +2*frame_stride ... (n_frames of them) to
  * the accumulation buffer instead of keeping a running mean.  Summing the

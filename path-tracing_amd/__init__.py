@@ -65,6 +65,7 @@ API_SYMBOLS = [
     "pt_last_error", "pt_bvh_build", "pt_free",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
+    "pt_render_frames_static", "pt_static_scratch_bytes",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -108,6 +109,9 @@ def load_library():
     L.pt_set_camera.argtypes = [C.c_void_p, fp, fp]
     L.pt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.pt_render_frames_sum.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.pt_render_frames_static.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.pt_static_scratch_bytes.argtypes = []
+    L.pt_static_scratch_bytes.restype = C.c_size_t
     L.pt_scale_accum.argtypes = [C.c_void_p, C.c_float]
     L.pt_set_pixel_shard.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
     L.pt_probe_intersections.argtypes = [C.c_void_p, fp, fp, fp, fp, C.c_uint32, fp]
@@ -322,6 +326,10 @@ class Renderer:
 
     def render_frames(self, first_frame_count, n_frames):
         self._check(self._L.pt_render_frames(self._ctx, int(first_frame_count), int(n_frames)))
+
+    def render_frames_static(self, first_frame_count, n_frames):
+        """pt_render_frames without any device allocation: working state in the library's static scratch."""
+        self._check(self._L.pt_render_frames_static(self._ctx, int(first_frame_count), int(n_frames)))
 
     def render_frames_sum(self, first_frame_count, n_frames, frame_stride=1):
         self._check(self._L.pt_render_frames_sum(self._ctx, int(first_frame_count), int(n_frames), int(frame_stride)))

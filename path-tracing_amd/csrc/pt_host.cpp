@@ -17,7 +17,36 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
+
+/*
+ * Device memory for pt_render_frames_static, the entry point that allocates nothing: the hit list,
+ * the control words, the per-pixel tables and the sample buffer of one batch of frames live in this
+ * array instead of in buffers the context owns.  Every GPU the library runs on holds its own copy
+ * (at its own address) until the process ends.  In host code the array's name is only a handle for
+ * hipGetSymbolAddress: kernels, memsets and copies get the per-device address kept in
+ * g_static_scratch[], looked up once per device in pt_create.
+ */
+#define PT_STATIC_SCRATCH_BYTES (64u << 20)
+#define PT_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[PT_STATIC_SCRATCH_BYTES];
+
 namespace {
+
+std::mutex g_static_scratch_mutex;
+unsigned char *g_static_scratch[PT_MAX_DEVICES];     /* device address of `scratch` on each GPU, or null */
+
+/* with `device` current */
+hipError_t static_scratch_lookup(int device) {
+    if (device < 0 || device >= PT_MAX_DEVICES) return hipSuccess;      /* such a device has no static path */
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    if (g_static_scratch[device]) return hipSuccess;
+    void *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_static_scratch[device] = (unsigned char *)ptr;
+    return hipSuccess;
+}
 
 thread_local std::string g_create_error;
 
@@ -318,10 +347,53 @@ struct Timed {
     void done() { if (ok) { (void)hipEventRecord(ep.stop, c->stream); c->pending.push_back(ep); } }
 };
 
-int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, uint32_t mode) {
+/* where a render keeps its per-batch state when that is not the context's own buffers */
+struct WorkBuffers {
+    PTControl *ctrl; uint32_t *pixel_hit; float4 *pixel_const; PTHitRecord *hits; float4 *samples;
+    uint32_t max_batch;
+};
+
+size_t round256(size_t n) { return (n + 255u) & ~(size_t)255u; }
+
+/* Cuts the static scratch of this context's GPU into the buffers of one batch.  Fails when not even
+ * one frame fits. */
+int static_work_buffers(pt_ctx *c, uint32_t n_frames, WorkBuffers &wb) {
+    unsigned char *base = (c->device >= 0 && c->device < PT_MAX_DEVICES) ? g_static_scratch[c->device] : nullptr;
+    if (!base) return fail(c, PT_ESTATE, "no static scratch on this device");
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    const size_t slots_per_frame = ((npix + 63) / 64 * 64) * c->params.rays_per_pixel;
+    const size_t per_frame = slots_per_frame * sizeof(float4);
+    size_t off = 0;
+    const size_t o_ctrl = off; off += round256(sizeof(PTControl));
+    const size_t o_hit = off; off += round256(npix * sizeof(uint32_t));
+    const size_t o_const = off; off += round256(npix * sizeof(float4));
+    const size_t o_hits = off; off += round256(npix * sizeof(PTHitRecord));
+    const size_t o_samples = off;
+    if (off + per_frame > PT_STATIC_SCRATCH_BYTES)
+        return fail(c, PT_EINVAL, "pt_render_frames_static: one frame of " + std::to_string(c->params.width) + "x" +
+                    std::to_string(c->params.height) + " at " + std::to_string(c->params.rays_per_pixel) + " rays per pixel needs " +
+                    std::to_string(off + per_frame) + " bytes of scratch, the static array holds " +
+                    std::to_string((size_t)PT_STATIC_SCRATCH_BYTES) + " (use pt_render_frames)");
+    size_t nb = (PT_STATIC_SCRATCH_BYTES - off) / per_frame;
+    if (nb > 0xffffffffull / slots_per_frame) nb = 0xffffffffull / slots_per_frame;
+    if (nb > 64) nb = 64;
+    if (nb > n_frames) nb = n_frames ? n_frames : 1;
+    wb.ctrl = (PTControl *)(base + o_ctrl);
+    wb.pixel_hit = (uint32_t *)(base + o_hit);
+    wb.pixel_const = (float4 *)(base + o_const);
+    wb.hits = (PTHitRecord *)(base + o_hits);
+    wb.samples = (float4 *)(base + o_samples);
+    wb.max_batch = (uint32_t)nb;
+    return PT_OK;
+}
+
+/* wb == nullptr: the context's own buffers, kernels timed with events.  wb != nullptr (the static
+ * path): no events either, so that the call creates no runtime object at all. */
+int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, uint32_t mode, const WorkBuffers *wb = nullptr) {
     if (!c) return PT_EINVAL;
     if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t max_batch = wb ? wb->max_batch : c->max_batch;
     const bool exact = (c->params.flags & PT_FLAG_EXACT_MATH) != 0;
     const bool count = (c->params.flags & PT_FLAG_COUNT_WORK) != 0;
     /* Frames are rendered in batches: camera and scene are constant within the call, so the
@@ -329,12 +401,23 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
      * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
      * and the resolve kernel folds the frames into the accumulation buffer in frame order. */
     for (uint32_t done = 0; done < n_frames;) {
-        uint32_t batch = n_frames - done < c->max_batch ? n_frames - done : c->max_batch;
+        uint32_t batch = n_frames - done < max_batch ? n_frames - done : max_batch;
         PTKernelParams k;
         fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
-        HIP_TRY(c, hipMemsetAsync(c->d_ctrl, 0, sizeof(PTControl), c->stream));
+        if (wb) { k.ctrl = wb->ctrl; k.pixel_hit = wb->pixel_hit; k.pixel_const = wb->pixel_const; k.hits = wb->hits; k.samples = wb->samples; }
+        /* the control words must start at zero; everything else a batch reads it has written itself
+         * (the hit list up to hit_count, pixel_hit of every pixel, pixel_const of miss pixels, one sample
+         * per path), so stale contents of an earlier call are never seen */
+        HIP_TRY(c, hipMemsetAsync(k.ctrl, 0, sizeof(PTControl), c->stream));
         if (c->shard_world > 1)     /* pixels of other ranks: marked "not mine" (0xfefefefe), the primary kernel visits owned tiles only */
-            HIP_TRY(c, hipMemsetAsync(c->d_pixel_hit, 0xfe, (size_t)c->params.width * c->params.height * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(k.pixel_hit, 0xfe, (size_t)c->params.width * c->params.height * sizeof(uint32_t), c->stream));
+        if (wb) {
+            HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream));
+            HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream));
+            HIP_TRY(c, pt_launch_resolve(k, c->stream));
+            done += batch;
+            continue;
+        }
         { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream)); t.done(); }
         { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream)); t.done(); }
         { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
@@ -415,6 +498,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         { fail(nullptr, PT_EHIP, std::string("unsupported GPU architecture ") + prop.gcnArchName + " (built for gfx950)"); pt_destroy(c); return PT_EHIP; }
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = static_scratch_lookup(device_ordinal)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
     const size_t npix = (size_t)params->width * params->height;
     if ((e = hipMalloc(&c->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
@@ -519,6 +603,17 @@ int pt_set_camera(pt_ctx *c, const float position[3], const float rotation_degre
 int pt_render_frames(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames) {
     return render_impl(c, first_frame_count, n_frames, 1, 0);
 }
+
+int pt_render_frames_static(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames) {
+    if (!c) return PT_EINVAL;
+    if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
+    WorkBuffers wb;
+    int rc = static_work_buffers(c, n_frames, wb);
+    if (rc) return rc;
+    return render_impl(c, first_frame_count, n_frames, 1, 0, &wb);
+}
+
+size_t pt_static_scratch_bytes(void) { return (size_t)PT_STATIC_SCRATCH_BYTES; }
 
 int pt_render_frames_sum(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frames, uint32_t frame_stride) {
     if (c && frame_stride == 0) return fail(c, PT_EINVAL, "frame_stride must be >= 1");

@@ -1,28 +1,36 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s of the path-tracing hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--shard pixels|frames]
 
 A "step" is one complete render of the configuration (default: benchmark configuration 4,
 dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
 max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
-one process per GPU with torch.distributed.run; the image is sharded over ranks in
-8x8-pixel tiles (every rank renders all frames of its tiles, running mean as on one
-GPU) and the zero-initialised buffers are assembled with one RCCL sum reduce to rank 0
-per step (strong scaling: total samples fixed; the result equals the single-GPU image
-bit for bit).  Rank 0 prints ONE JSON line.
+one process per GPU with torch.distributed.run; the render is sharded over ranks either in
+8x8-pixel tiles (default: every rank renders all frames of its tiles, running mean as on one
+GPU, result equal to the single-GPU image bit for bit) or by frames (--shard frames: rank r
+renders frames r, r+N, ... into a sum; the split the reference's accumulation unit suggests),
+and the buffers are combined with ONE RCCL sum reduce to rank 0 per step (strong scaling:
+total samples fixed).  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     - path (bounce) kernel: algorithmic bytes of the casts it executes
-                 (36 B per box test + 36 B per triangle test + 48 B per sphere per
-                 cast, reference layout and visit order, counted by an instrumented
-                 run of the same launches) / mean launch duration from HIP events on
-                 the library's stream, against the 8 TB/s HBM3E figure.
+  roofline     - the path (bounce) kernel, 98 % of the time.  It streams nothing: its working set
+                 sits in L2 / Infinity Cache and what it asks of the chip is 64-lane GATHER
+                 instructions (four per BVH node visit).  The unit they all pass through is the
+                 CU's texture addresser (TA); `frac` is the share of the launch during which the
+                 TAs were busy (TA_TA_BUSY from the committed counter pass of the same workload and
+                 kernel source, profiles/path_kernel_pmc.json, scaled to the launch time measured
+                 here with HIP events).  HBM, Infinity Cache, L2 and VALU utilisation are listed
+                 next to it under `other_bounds`; the algorithmic bytes (reference layout: 36 B per
+                 box test, 36 B per triangle test, 48 B per sphere per cast, counted by an
+                 instrumented run of the same launches) are reported as `algorithmic_over_actual`
+                 against the bytes that really left the L2s.
   cpu_baseline - the CPU oracle (oracle/, a C restatement of the reference shader;
                  the reference itself cannot run here) on a bounded sample of the
                  same workload, rank 0 at N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,6 +44,22 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec
 L2_PEAK_GBS = 34500.0        # aggregate L2, measured figure of the microarchitecture guide
 MALL_PEAK_GBS = 8600.0       # Infinity Cache random-row gather figure of the same guide
+# kernel-time efficiency of pixel sharding predicted from single-GPU runs of one rank's share
+# (tools/shard_cost.py): the persistent kernel's tail does not shrink with the image
+PREDICTED_EFFICIENCY = {"2": 0.975, "4": 0.94, "8": 0.86}
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("pt_kernels.hip", "pt_internal.h", "pt_exact_div.h", "pt_portable_math.h"):
+        h.update(open(os.path.join(ROOT, "path-tracing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def metric_name(cfg):
+    res = {(1920, 1080): "1080p", (3840, 2160): "4K"}.get((cfg["width"], cfg["height"]), "%dx%d" % (cfg["width"], cfg["height"]))
+    mesh = {"dragon_800k_synth": "dragon_800k"}.get(cfg["mesh"], cfg["mesh"])
+    return "Msamples/s at %s %s, %d bounces" % (res, mesh, cfg["max_bounce_count"])
 
 
 def main():
@@ -44,6 +68,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--shard", choices=("pixels", "frames"), default="pixels",
+                    help="N > 1: 8x8-pixel tiles (bit-identical image) or the frames of the render (sum + scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting pass")
     args = ap.parse_args()
@@ -63,6 +89,7 @@ def main():
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
+        os.environ.setdefault("PT_SAMPLE_BUDGET_MB", "8192")      # N contexts share one GPU's memory
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -92,11 +119,16 @@ def main():
 
     r = make_renderer()
     info = r.scene_info()
-    sharded = ShardedRenderer(r, rank, world, collective="reduce") if world > 1 else None     # the image ends on rank 0
+    # the image ends on rank 0
+    sharded = ShardedRenderer(r, rank, world, mode=args.shard, collective="reduce") if world > 1 else None
+    phase = {"render_s": 0.0, "collective_s": 0.0}
 
-    def step():
+    def step(timed=False):
         if sharded is not None:
             sharded.render(0, n_frames)
+            if timed:
+                for k in phase:
+                    phase[k] += sharded.last_timing[k]
         else:
             r.render_frames(0, n_frames)          # the reference protocol: running mean over frames
             r.synchronize()
@@ -113,20 +145,35 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     timing = r.timing()
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = {"rank": rank, "path_ms_per_step": timing["path_ms"] / args.steps,
+                "primary_ms_per_step": timing["primary_ms"] / args.steps,
+                "resolve_ms_per_step": timing["resolve_ms"] / args.steps,
+                "render_ms_per_step": phase["render_s"] / args.steps * 1e3,
+                "collective_ms_per_step": phase["collective_s"] / args.steps * 1e3,
+                "frames_per_step": timing["frames"] / args.steps}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     result = None
     if rank == 0:
         value = samples_per_step * args.steps / elapsed / 1e6
+        if world == 1:
+            parallelism = "single GPU, running mean"
+        elif args.shard == "pixels":
+            parallelism = "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world
+        else:
+            parallelism = "frames f = rank (mod %d) summed per GPU, one RCCL sum reduce to rank 0 per step, scaled by 1/frames" % world
         result = {
-            "metric": "Msamples/s at 1080p dragon_800k, 8 bounces",
+            "metric": metric_name(cfg),
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -139,52 +186,103 @@ def main():
                 "resolution": [W, H], "spp": spp, "frames": n_frames, "rays_per_pixel": rpp,
                 "max_bounce_count": cfg["max_bounce_count"], "triangles": int(len(tris)),
                 "bvh_nodes": int(len(bvh)), "bvh_depth": info["bvh_depth"], "spheres": int(len(spheres)),
-                "parallelism": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world
-                               if world > 1 else "single GPU, running mean",
+                "parallelism": parallelism,
             },
             "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])
                                     for k in ("primary_ms", "path_ms", "resolve_ms")},
             "kernel_launches_per_step": timing["batches"] / max(1, args.steps),
         }
+        if world > 1:
+            result["per_rank"] = per_rank
+            result["collective_ms_per_step"] = max(p["collective_ms_per_step"] for p in per_rank)
+            result["predicted_efficiency"] = dict(PREDICTED_EFFICIENCY, note="pixel sharding, kernel time only, from "
+                                                  "single-GPU runs of one rank's share (tools/shard_cost.py); no N > 1 "
+                                                  "run on hardware has been compared with it yet")
 
     # ---- roofline of the dominant kernel (rank 0) -------------------------
     if rank == 0:
-        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-                "traffic": None, "kernel": "path_kernel"}
+        avg_ms = timing["path_ms"] / max(1, timing["batches"])
+        roof = {"kernel": "path_kernel", "bound": "vector-memory address path (TA)", "achieved": None, "peak": None,
+                "unit": "G gather instructions/s", "frac": None, "traffic": None,
+                "avg_launch_ms": avg_ms, "launches_timed": int(timing["batches"])}
+        launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
+        ppath = os.path.join(ROOT, "profiles", "path_kernel_pmc.json")
+        pj = None
+        if os.path.exists(ppath):
+            with open(ppath) as f:
+                pj = json.load(f)
+        if pj and pj.get("workload") == cfg["name"] and world == 1 and "path_kernel" in pj and timing["batches"]:
+            d = pj["path_kernel"]
+            live_s = avg_ms * 1e-3
+            roof["counter_pass"] = {"file": "profiles/path_kernel_pmc.json", "launch_ms_in_pass": d["trace_mean_ms"],
+                                    "clock_ghz_in_pass": d["clock_ghz"],
+                                    "kernel_source_matches": pj.get("source_hash") == kernel_source_hash()}
+            if "ta_busy_cycles_per_cu" in d:
+                ta_busy_s = d["ta_busy_cycles_per_cu"] / (d["clock_ghz"] * 1e9)
+                roof["achieved"] = d["vmem_read_instructions"] / live_s / 1e9
+                # the rate at which the TAs would finish this launch's instruction stream if they never idled
+                roof["peak"] = d["vmem_read_instructions"] / ta_busy_s / 1e9
+                roof["frac"] = min(1.0, ta_busy_s / live_s)
+                roof["gather_instructions_per_launch"] = d["vmem_read_instructions"]
+                roof["l1_tag_lookups_per_instruction"] = d["l1_tag_lookups"] / d["vmem_read_instructions"]
+            other = {}
+            if "hbm_side_bytes" in d:
+                roof["traffic"] = d["hbm_side_bytes"]
+                gbs = d["hbm_side_bytes"] / live_s / 1e9
+                other["hbm"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                "note": "bytes on the memory side of the L2s (Infinity Cache hits included)"}
+                other["infinity_cache"] = {"achieved": gbs, "peak": MALL_PEAK_GBS, "unit": "GB/s", "frac": gbs / MALL_PEAK_GBS}
+            if "l2_read_bytes" in d:
+                gbs = d["l2_read_bytes"] / live_s / 1e9
+                other["l2"] = {"achieved": gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": gbs / L2_PEAK_GBS,
+                               "l1_hit_rate": d["l1_hit_rate"], "l2_hit_rate": d.get("l2_hit_rate")}
+            if "valu_busy_low" in d:
+                scale = d["trace_mean_ms"] / avg_ms
+                other["valu"] = {"frac_low": d["valu_busy_low"] * scale, "frac_high": d["valu_busy_high"] * scale,
+                                 "lane_utilisation": d["valu_lane_utilisation"],
+                                 "note": "issue cycles / SIMD cycles: 2 per plain and 4 per packed-f32 instruction "
+                                         "(tools/ubench/valu_rate); low = all plain, high = SQ_ACTIVE_INST_VALU quad-cycles"}
+            roof["other_bounds"] = other
+        elif world > 1:
+            roof["note"] = "the counter pass describes the single-GPU launch shape; see per_rank for this run"
         if not args.no_count and timing["frames"]:
             rc = make_renderer(pkg.PT_FLAG_COUNT_WORK)
-            frames_local = n_frames
-            rc.set_pixel_shard(rank, world)          # the launches this rank timed
-            rc.render_frames(0, n_frames)
+            if world > 1 and args.shard == "pixels":
+                rc.set_pixel_shard(rank, world)          # the launches this rank timed
+                rc.render_frames(0, n_frames)
+                frames_local = n_frames
+            elif world > 1:
+                frames_local = len(range(rank, n_frames, world))
+                rc.render_frames_sum(rank, frames_local, world)
+            else:
+                rc.render_frames(0, n_frames)
+                frames_local = n_frames
             cnt = rc.counters()
             rc.close()
             S = len(spheres)
             path_bytes = 36 * cnt["path_kernel_box_tests"] + 36 * cnt["path_kernel_tri_tests"] \
                 + 48 * S * cnt["path_kernel_ray_casts"]
-            launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
             per_launch = path_bytes / launches_per_step
-            avg_ms = timing["path_ms"] / timing["batches"]
-            achieved = per_launch / (avg_ms * 1e-3) / 1e9
-            all_bytes = 36 * cnt["box_tests"] + 36 * cnt["tri_tests"] + 48 * S * cnt["ray_casts"] \
-                + 32 * W * H * frames_local // world
+            pixels_local = W * H // world if (world > 1 and args.shard == "pixels") else W * H
+            # casts that ran: the path kernel's, plus one primary cast per pixel and batch of frames
+            executed = cnt["path_kernel_ray_casts"] + pixels_local * launches_per_step
             roof.update({
-                "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": per_launch, "avg_launch_ms": avg_ms,
-                "launches_timed": int(timing["batches"]), "frames_per_launch": frames_local / launches_per_step,
+                "algorithmic_bytes_per_launch": per_launch,
+                "algorithmic_GBps": per_launch / (avg_ms * 1e-3) / 1e9,
+                "algorithmic_bytes_note": "reference layout and visit order: 36 B per box test + 36 B per triangle test + "
+                                          "48 B per sphere per cast; served almost entirely by the vector L1s, so this is "
+                                          "not a traffic figure",
+                "algorithmic_over_actual": per_launch / roof["traffic"] if roof["traffic"] else None,
+                "frames_per_launch": frames_local / launches_per_step,
                 "ray_casts_per_launch": cnt["path_kernel_ray_casts"] / launches_per_step,
                 "box_tests_per_cast": cnt["path_kernel_box_tests"] / max(1, cnt["path_kernel_ray_casts"]),
                 "tri_tests_per_cast": cnt["path_kernel_tri_tests"] / max(1, cnt["path_kernel_ray_casts"]),
-                "frac_of_l2_peak": achieved / L2_PEAK_GBS, "frac_of_mall_peak": achieved / MALL_PEAK_GBS,
-                "whole_frame_algorithmic_bytes": all_bytes / frames_local,
-                "reference_ray_casts_per_step": cnt["ray_casts"] * world,       # rank 0's share x ranks
-                "rays_per_second": cnt["ray_casts"] * world * args.steps / elapsed,
+                "executed_ray_casts_per_step": executed * world,         # rank 0's share x ranks
+                "rays_per_second": executed * world * args.steps / elapsed,
+                "reference_ray_casts_per_step": cnt["ray_casts"] * world,
+                "reference_ray_casts_note": "casts the reference shader would make for the same image (it repeats the "
+                                            "primary cast for every sample); not used for rays_per_second",
             })
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath) and world == 1:      # collected for the single-GPU launch shape
-                with open(tpath) as f:
-                    tj = json.load(f)
-                if tj.get("workload") == cfg["name"]:
-                    roof["traffic"] = tj.get("path_kernel_hbm_bytes_per_launch")
         result["roofline"] = roof
 
     # ---- CPU baseline (rank 0, N = 1 only) --------------------------------
@@ -195,7 +293,8 @@ def main():
             avail = len(os.sched_getaffinity(0))
         except AttributeError:
             avail = os.cpu_count() or 1
-        cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", avail)), 16))
+        # the box gives a one-GPU job 16 host cores and says so in OMP_NUM_THREADS
+        cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", "16"))))
         op = oracle.default_params(width=W, height=H, rays_per_pixel=rpp, max_bounce_count=cfg["max_bounce_count"])
         sc = oracle.scene(spheres, tris, bvh)
         cpu_frames = min(n_frames, 8)      # ~10-20 s of CPU work on 16 cores
@@ -217,6 +316,8 @@ def main():
         err = np.abs(gimg - acc[..., :3])
         ok = (err <= 2e-3 * np.abs(acc[..., :3]) + 1e-4).all(axis=-1).mean()
         result["parity_spot_check"] = {"frames": cpu_frames, "pixels_within_2e-3_rel": float(ok),
+                                       "rmse_over_mean": float(np.sqrt(np.mean((gimg.astype(np.float64) - acc[..., :3]) ** 2))
+                                                               / acc[..., :3].mean()),
                                        "mean_rel_err_of_image_mean": float(abs(gimg.mean() - acc[..., :3].mean()) / acc[..., :3].mean())}
 
     r.close()

@@ -49,7 +49,7 @@ typedef struct pt_ctx pt_ctx;
  * src/shaders/shader.wgsl:24-37 (counts, bounces, rays per pixel, screen size,
  * fov), :48-54 (environment) and the triangle material hard-coded in
  * ray_triangle, :283-286.  Counts of spheres/triangles/nodes are taken from
- * pt_upload_scene instead, and bvh_max_depth is derived from the node file.
+ * pt_upload_scene instead.
  */
 typedef struct pt_params {
     uint32_t width, height;          /* screen_size, shader.wgsl:35 */
@@ -67,6 +67,10 @@ typedef struct pt_params {
     float sun_intensity;             /* shader.wgsl:52 */
     float sun_focus;                 /* shader.wgsl:53 */
     uint32_t use_environment_lighting; /* shader.wgsl:54 */
+    float far_distance;              /* shader.wgsl:142,177 (1000000.0): distance of "no hit yet"; nothing at or beyond it is hit */
+    uint32_t bvh_max_depth;          /* shader.wgsl:30: the shader's stack holds bvh_max_depth + 1 entries (:170).  0 = take the
+                                        depth of the uploaded node file; otherwise a node file deeper than this is refused at
+                                        upload (the shader would overrun its stack) */
     uint32_t flags;                  /* PT_FLAG_* */
 } pt_params;
 

@@ -80,6 +80,7 @@ void orc_default_params(orc_params *p) {
     p->sun_dir[0] = 0.0f; p->sun_dir[1] = -0.4f; p->sun_dir[2] = 0.5f;              /* :51 */
     p->sun_intensity = 3.0f; p->sun_focus = 200.0f;                                 /* :52-53 */
     p->use_environment_lighting = 1;                                                /* :54 */
+    p->far_distance = ORC_FAR;
 }
 
 /* ---- RNG: shader.wgsl:351-375 ---- */
@@ -257,7 +258,7 @@ void orc_ray_triangle_bvh(const orc_params *p, const orc_scene *s, const float o
     int stack_index = 0;
     node_stack[stack_index++] = 0;
     hit_clear(result);
-    result->distance = ORC_FAR;
+    result->distance = p->far_distance;
     uint64_t boxes = 0, tris = 0, popped = 0, max_stack = 1;
 
     while (stack_index > 0) {
@@ -311,7 +312,7 @@ void orc_ray_triangles_brute(const orc_params *p, const orc_scene *s, const floa
                              const float dir[3], orc_hit *result) {
     orc_v3 o = from3(origin), d = from3(dir);
     hit_clear(result);
-    result->distance = ORC_FAR;
+    result->distance = p->far_distance;
     for (uint32_t i = 0; i < s->triangle_count; i++) {
         orc_hit th;
         ray_triangle(p, o, d, s->triangles + 9 * (size_t)i, &th);
@@ -327,7 +328,7 @@ void orc_calculate_ray_collision(const orc_params *p, const orc_scene *s, const 
                                  const float dir[3], orc_hit *closest, orc_counters *c) {
     orc_v3 o = from3(origin), d = from3(dir);
     hit_clear(closest);
-    closest->distance = ORC_FAR;
+    closest->distance = p->far_distance;
     for (uint32_t i = 0; i < s->sphere_count; i++) {
         orc_hit h;
         ray_sphere(o, d, s->spheres + 12 * (size_t)i, &h);

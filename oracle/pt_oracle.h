@@ -72,6 +72,7 @@ typedef struct {
     float sun_dir[3];           /* shader.wgsl:51, not normalised */
     float sun_intensity, sun_focus; /* shader.wgsl:52-53 */
     uint32_t use_environment_lighting; /* shader.wgsl:54 */
+    float far_distance;         /* 1000000.0: "no hit yet" distance of calculate_ray_collision and ray_triangle_bvh (shader.wgsl:142,177) */
 } orc_params;
 
 typedef struct {

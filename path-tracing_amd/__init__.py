@@ -34,7 +34,8 @@ class PtParams(C.Structure):
         ("tri_emission_strength", C.c_float), ("tri_smoothness", C.c_float),
         ("sky_horizon", C.c_float * 3), ("sky_zenith", C.c_float * 3), ("ground", C.c_float * 3),
         ("sun_dir", C.c_float * 3), ("sun_intensity", C.c_float), ("sun_focus", C.c_float),
-        ("use_environment_lighting", C.c_uint32), ("flags", C.c_uint32),
+        ("use_environment_lighting", C.c_uint32), ("far_distance", C.c_float), ("bvh_max_depth", C.c_uint32),
+        ("flags", C.c_uint32),
     ]
 
 

@@ -26,7 +26,7 @@
  *   predicate use the plain division, so results never depend on this file.
  *
  * The equivalence is also checked by brute force on the CPU
- * (tests/test_exact_division.py: 10^9 random and adversarial near-midpoint
+ * (tests/test_exact_division.py: 10^8 random cases plus adversarial near-midpoint
  * cases) and, implicitly, by every bit-exact GPU-vs-oracle test.
  */
 #ifndef PT_EXACT_DIV_H

@@ -74,7 +74,14 @@ struct pt_ctx {
     uint32_t *d_spill = nullptr;
     uint32_t *d_pixel_hit = nullptr;
     float4 *d_pixel_const = nullptr;
-    uint32_t max_batch = 1;            /* frames whose samples fit the sample buffer */
+    size_t sample_slots = 0;           /* float4 slots d_samples holds (allocated by the render calls, grow-only) */
+    size_t sample_budget = 0;          /* most bytes d_samples may take */
+    /* Batches whose worst case (every pixel a hit pixel) stays below this allocate for the worst case and
+     * stay asynchronous; larger ones wait for the primary pass and size the buffer by the hit count.
+     * 1 GiB; PT_SMALL_SAMPLE_MB overrides (0: always by hit count). */
+    size_t small_sample_bytes = (size_t)1 << 30;
+    uint32_t batch_cap = 1;            /* most frames one batch may hold (32-bit slot numbers, at most 64) */
+    uint32_t *h_hit_count = nullptr;   /* pinned host word the hit count of a batch is copied to */
     unsigned long long *d_counters = nullptr;
     int32_t *d_ids = nullptr;
     float *d_dist = nullptr;
@@ -141,6 +148,9 @@ bool leaf_ref(const float *node, uint32_t tri_count, Repacked &out, uint32_t &re
     if (first >= (1u << 24)) { why = "triangle index does not fit 24 bits"; return false; }
     if (count >= PT_REF_COUNT_ESCAPE) {
         if (out.big.empty()) out.big.assign(tri_count ? tri_count : 1, 0);
+        /* the side table is keyed by the first triangle: two big leaves that start at the same triangle
+         * with different lengths (a node file with overlapping ranges) cannot both be represented */
+        if (out.big[first] != 0 && out.big[first] != count) { why = "two leaves of 127 or more triangles start at the same triangle with different counts"; return false; }
         out.big[first] = count;
         ref = PT_REF_LEAF | (PT_REF_COUNT_ESCAPE << 24) | first;
     } else {
@@ -228,7 +238,8 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
         rec_of[f.node] = f.rec;
         st.pop_back();
     }
-    if (out.inner.size() >= 0x80000000u) { why = "too many inner nodes"; return false; }
+    /* record offsets (index * 64) are 32-bit in the kernels */
+    if (out.inner.size() >= (1u << 26)) { why = "more than 2^26 reachable inner nodes"; return false; }
     out.root_ref = rec_of[0];
     out.depth = height[0];
     return true;
@@ -258,6 +269,9 @@ int validate_params(const pt_params *p, std::string &why) {
     if (p->rays_per_pixel == 0 || p->rays_per_pixel > 1024) { why = "rays_per_pixel must be in 1..1024"; return PT_EINVAL; }
     if (p->max_bounce_count > 1000000) { why = "max_bounce_count too large"; return PT_EINVAL; }
     if (!(p->fov_degrees > 0.0f && p->fov_degrees < 180.0f)) { why = "fov_degrees must be in (0,180)"; return PT_EINVAL; }
+    /* a missed box reports 999999999.0 (shader.wgsl:254) and must never pass `dst < far` */
+    if (!(p->far_distance > 0.0f && p->far_distance <= 999999999.0f)) { why = "far_distance must be in (0, 999999999]"; return PT_EINVAL; }
+    if (p->bvh_max_depth > 4096) { why = "bvh_max_depth too large"; return PT_EINVAL; }
     return PT_OK;
 }
 
@@ -303,6 +317,7 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.neg_sun[0] = -(sx * inv); k.neg_sun[1] = -(sy * inv); k.neg_sun[2] = -(sz * inv);
     k.sun_intensity = p.sun_intensity; k.sun_focus = p.sun_focus;
     k.use_env = p.use_environment_lighting ? 1u : 0u;
+    k.far_distance = p.far_distance;
     k.sphere_count = c->sphere_count;
     k.root_ref = c->root_ref;
     k.stack_entries = (uint32_t)c->stack_entries;
@@ -387,21 +402,58 @@ int static_work_buffers(pt_ctx *c, uint32_t n_frames, WorkBuffers &wb) {
     return PT_OK;
 }
 
+/* Makes d_samples hold at least `slots` float4 values.  The old contents are not kept (a batch writes
+ * every sample it reads).  hipErrorOutOfMemory is returned as such so that the caller can try a smaller batch. */
+hipError_t ensure_sample_slots(pt_ctx *c, size_t slots) {
+    if (slots <= c->sample_slots) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(c->stream);        /* earlier batches may still read the old buffer */
+    if (e != hipSuccess) return e;
+    dev_free(c->d_samples);
+    c->sample_slots = 0;
+    e = hipMalloc(&c->d_samples, slots * sizeof(float4));
+    if (e != hipSuccess) { (void)hipGetLastError(); c->d_samples = nullptr; return e; }
+    c->sample_slots = slots;
+    return hipSuccess;
+}
+
+
 /* wb == nullptr: the context's own buffers, kernels timed with events.  wb != nullptr (the static
  * path): no events either, so that the call creates no runtime object at all. */
 int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, uint32_t mode, const WorkBuffers *wb = nullptr) {
     if (!c) return PT_EINVAL;
     if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
     HIP_TRY(c, hipSetDevice(c->device));
-    const uint32_t max_batch = wb ? wb->max_batch : c->max_batch;
     const bool exact = (c->params.flags & PT_FLAG_EXACT_MATH) != 0;
     const bool count = (c->params.flags & PT_FLAG_COUNT_WORK) != 0;
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    const size_t rpp = c->params.rays_per_pixel;
+    const size_t worst_per_frame = ((npix + 63) / 64 * 64) * rpp;      /* slots when every pixel is a hit pixel */
+    uint32_t max_batch = wb ? wb->max_batch : c->batch_cap;
+    if (!wb) {      /* the budget holds for the worst case */
+        size_t by_budget = c->sample_budget / (worst_per_frame * sizeof(float4));
+        if (by_budget < 1) by_budget = 1;
+        if (by_budget < max_batch) max_batch = (uint32_t)by_budget;
+    }
     /* Frames are rendered in batches: camera and scene are constant within the call, so the
      * primary rays (identical for every sample of every frame, shader.wgsl:80-101) are cast once
      * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
      * and the resolve kernel folds the frames into the accumulation buffer in frame order. */
     for (uint32_t done = 0; done < n_frames;) {
         uint32_t batch = n_frames - done < max_batch ? n_frames - done : max_batch;
+        bool by_hit_count = false;
+        if (!wb) {
+            const size_t worst = worst_per_frame * batch;
+            if (worst > c->sample_slots) {
+                /* counting contexts always take the worst case: their primary pass must run exactly once per batch */
+                if (worst * sizeof(float4) <= c->small_sample_bytes || count) {
+                    hipError_t e = ensure_sample_slots(c, worst);
+                    if (e == hipErrorOutOfMemory && batch > 1) { max_batch = batch / 2; continue; }
+                    if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");
+                } else {
+                    by_hit_count = true;
+                }
+            }
+        }
         PTKernelParams k;
         fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
         if (wb) { k.ctrl = wb->ctrl; k.pixel_hit = wb->pixel_hit; k.pixel_const = wb->pixel_const; k.hits = wb->hits; k.samples = wb->samples; }
@@ -410,7 +462,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
          * per path), so stale contents of an earlier call are never seen */
         HIP_TRY(c, hipMemsetAsync(k.ctrl, 0, sizeof(PTControl), c->stream));
         if (c->shard_world > 1)     /* pixels of other ranks: marked "not mine" (0xfefefefe), the primary kernel visits owned tiles only */
-            HIP_TRY(c, hipMemsetAsync(k.pixel_hit, 0xfe, (size_t)c->params.width * c->params.height * sizeof(uint32_t), c->stream));
+            HIP_TRY(c, hipMemsetAsync(k.pixel_hit, 0xfe, npix * sizeof(uint32_t), c->stream));
         if (wb) {
             HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream));
             HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream));
@@ -419,6 +471,28 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
             continue;
         }
         { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream)); t.done(); }
+        if (by_hit_count) {
+            /* a large render: wait for the primary pass and make room for the paths of the pixels it hit */
+            HIP_TRY(c, hipMemcpyAsync(c->h_hit_count, &c->d_ctrl->hit_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const size_t hits = *c->h_hit_count;
+            size_t need = ((hits + 63) / 64 * 64) * rpp * batch;
+            if (need > c->sample_slots) {
+                size_t want = need + need / 8;              /* headroom: a camera move changes the hit count */
+                const size_t worst = worst_per_frame * batch;
+                if (want > worst) want = worst;
+                hipError_t e = ensure_sample_slots(c, want);
+                if (e == hipErrorOutOfMemory && want > need) e = ensure_sample_slots(c, need);
+                if (e == hipErrorOutOfMemory && batch > 1) {
+                    /* start this batch again with half the frames (the primary pass does not depend on
+                     * the batch length except for the work counters, which such contexts do not keep) */
+                    max_batch = batch / 2;
+                    continue;
+                }
+                if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");
+                k.samples = c->d_samples;
+            }
+        }
         { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream)); t.done(); }
         { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
         c->timing.frames += batch;
@@ -466,6 +540,8 @@ int pt_default_params(pt_params *p) {
     p->sun_dir[0] = 0.0f; p->sun_dir[1] = -0.4f; p->sun_dir[2] = 0.5f;
     p->sun_intensity = 3.0f; p->sun_focus = 200.0f;
     p->use_environment_lighting = 1;
+    p->far_distance = 1000000.0f;
+    p->bvh_max_depth = 0;
     p->flags = 0;
     return PT_OK;
 }
@@ -506,21 +582,24 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->d_accum = c->d_accum_own;
     if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
     if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
-    /* sample buffer: as many frames per batch as fit the budget (default 64 GiB of the 288 GB, PT_SAMPLE_BUDGET_MB) */
+    /* The sample buffer (one float4 per path of a batch of frames) is allocated by the render calls, for the
+     * frames actually asked for; here only its limits are fixed: at most PT_SAMPLE_BUDGET_MB (default 64 GiB
+     * of the 288 GB) and 64 frames per batch, and slot numbers must fit 32 bits. */
     {
         size_t budget = (size_t)64 << 30;
         if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
-        /* hit pixels are stored in interleaved groups of 64; slot numbers are 32-bit */
-        size_t slots_per_frame = ((npix + 63) / 64 * 64) * params->rays_per_pixel;
-        size_t per_frame = slots_per_frame * sizeof(float4);
-        size_t nb = budget / per_frame;
-        if (nb > 0xffffffffull / slots_per_frame) nb = 0xffffffffull / slots_per_frame;
-        if (nb < 1) nb = 1;
+        c->sample_budget = budget;
+        if (const char *ev = getenv("PT_SMALL_SAMPLE_MB")) { long v = atol(ev); if (v >= 0) c->small_sample_bytes = (size_t)v << 20; }
+        /* hit pixels are stored in interleaved groups of 64; the path kernel's queue arithmetic goes up to
+         * (hit pixels + 7) * frames * rays_per_pixel */
+        const size_t slots_per_frame = ((npix + 63) / 64 * 64 + 8) * params->rays_per_pixel;
+        size_t nb = 0xffffffffull / slots_per_frame;
+        if (nb < 1) { fail(nullptr, PT_EINVAL, "width * height * rays_per_pixel does not fit the 32-bit sample numbering"); pt_destroy(c); return PT_EINVAL; }
         if (nb > 64) nb = 64;
         if (const char *ev = getenv("PT_MAX_BATCH")) { long v = atol(ev); if (v >= 1 && (size_t)v < nb) nb = (size_t)v; }
-        c->max_batch = (uint32_t)nb;
-        if ((e = hipMalloc(&c->d_samples, per_frame * nb)) != hipSuccess) return bail(e, "hipMalloc(samples)");
+        c->batch_cap = (uint32_t)nb;
     }
+    if ((e = hipHostMalloc((void **)&c->h_hit_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(hit count)");
     if ((e = hipMalloc(&c->d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pixel_hit)");
     if ((e = hipMalloc(&c->d_pixel_const, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(pixel_const)");
     if ((e = hipMalloc(&c->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
@@ -545,6 +624,9 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     /* The shader needs array<i32, bvh_max_depth + 1> (shader.wgsl:170).  Here the near child is
      * never pushed, so at most one entry per level is live: depth entries (at least 1). */
     int need = rp.depth > 0 ? (int)rp.depth : 1;
+    if (c->params.bvh_max_depth != 0 && rp.depth > c->params.bvh_max_depth)
+        return fail(c, PT_EINVAL, "node file is " + std::to_string(rp.depth) + " levels deep, pt_params.bvh_max_depth is " +
+                    std::to_string(c->params.bvh_max_depth) + " (the shader's stack of bvh_max_depth + 1 entries would overflow)");
     if (need > pt_max_stack_entries())
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(rp.depth) + " exceeds the supported traversal stack");
     std::vector<PTTriRecord> trec;
@@ -841,6 +923,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
     dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill);
+    if (c->h_hit_count) (void)hipHostFree(c->h_hit_count);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -78,6 +78,7 @@ struct PTKernelParams {
     float tri_color[3], tri_emission_color[3], tri_emission_strength, tri_smoothness;
     float sky_horizon[3], sky_zenith[3], ground[3], neg_sun[3], sun_intensity, sun_focus;
     uint32_t use_env;
+    float far_distance;            /* "no hit yet" distance (shader.wgsl:142,177) */
     uint32_t sphere_count;
     uint32_t root_ref;
     uint32_t stack_entries;        /* LDS traversal stack depth per lane (>= depth of the node file) */
@@ -88,7 +89,7 @@ struct PTKernelParams {
     uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;
     uint32_t tris_bytes;           /* size of the triangle-record array (at most 2^24 x 48 bytes) */
-    uint32_t inner_bytes;          /* size of the inner-record array (below 2^32: at most 2^24 triangles) */
+    uint32_t inner_bytes;          /* size of the inner-record array (below 2^32: the upload refuses 2^26 or more inner records) */
     const PTTriRecord *tris;
     const float *spheres;
     const uint32_t *big_leaf_count;

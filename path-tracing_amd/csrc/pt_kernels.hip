@@ -32,7 +32,6 @@
 
 #pragma clang fp contract(off)
 
-#define PT_FAR 1000000.0f          /* shader.wgsl:142,177 */
 #define PT_BOX_MISS 999999999.0f   /* shader.wgsl:254 */
 #define PT_PI 3.14159f             /* shader.wgsl:36,365 */
 #define PT_NONE INT32_MIN
@@ -147,6 +146,9 @@ template <bool FAST>
 __device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y) {
     if (FAST) {
         f2 q = n * y;
+#ifdef PT_ABL_APPROX_DIV    /* timing probe only: the uncorrected product (results are no longer the shader's) */
+        return q;
+#endif
         f2 r = __builtin_elementwise_fma(-b, q, n);
         q = __builtin_elementwise_fma(r, y, q);
         r = __builtin_elementwise_fma(-b, q, n);
@@ -269,7 +271,7 @@ __device__ __forceinline__ V3 ray_dir(const RayPk &R) { return mk(R.dxy.x, R.dxy
 __device__ __forceinline__ void trav_begin(const PTKernelParams &P, uint32_t stack_bottom_offset, Trav &T) {
     T.cur = P.root_ref;
     T.sp = stack_bottom_offset;
-    T.best_t = PT_FAR;
+    T.best_t = P.far_distance;
     T.best_id = PT_NONE;
 }
 
@@ -344,7 +346,8 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
     {
         float xa, xb;
         float4 p0 = q0, p1 = q1, p2 = q2;
-        asm volatile("" : "+v"(p0.x), "+v"(p1.x), "+v"(p2.x));
+        asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w), "+v"(p1.x), "+v"(p1.y), "+v"(p1.z), "+v"(p1.w),
+                          "+v"(p2.x), "+v"(p2.y), "+v"(p2.z), "+v"(p2.w));       /* all twelve planes opaque: nothing of the first test can be reused */
         ray_box2<FAST>(T.R, p0, p1, p2, xa, xb);
         dst_a = fmin_(dst_a, fabsf(xa) + 3.0e38f);
         dst_b = fmin_(dst_b, fabsf(xb) + 3.0e38f);
@@ -439,7 +442,7 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
 
 /* the sphere loop of calculate_ray_collision, shader.wgsl:144-154 */
 __device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V3 d, float &best, int32_t &id) {
-    best = PT_FAR;
+    best = P.far_distance;
     id = PT_NONE;
     for (uint32_t k = 0; k < P.sphere_count; k++) {
         float dst;
@@ -453,7 +456,7 @@ __device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V
 template <bool COUNT>
 __device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveMem &M, bool active, V3 o, V3 d,
                                             float &t_out, int32_t &id_out, Counters &cn) {
-    float best = PT_FAR;
+    float best = P.far_distance;
     int32_t id = PT_NONE;
     const bool fast = P.fast_div && __all(!active || ray_div_safe(o, d));
     if (active) {
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 
     V3 ro = ld3(P.cam_pos), rd = mk(0.0f, 0.0f, -1.0f);
     uint32_t pixel_index = 0;
-    float t = PT_FAR;
+    float t = P.far_distance;
     int32_t id = PT_NONE;
     if (valid) primary_ray(P, px, py, rd, pixel_index);
     closest_hit<COUNT>(P, M, valid, ro, rd, t, id, cn);
@@ -708,10 +711,10 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
     bool drained = total == 0;
     uint32_t slot = 0, seed = 0, i = 0;
     V3 light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
-    float sph_t = PT_FAR;
+    float sph_t = P.far_distance;
     int32_t sph_id = PT_NONE;
     Trav T;      /* T.R is the lane's current ray: the only copy kept across the traversal loop */
-    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = PT_FAR; T.best_id = PT_NONE;
+    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = P.far_distance; T.best_id = PT_NONE;
     raypk_set(T.R, mk(0, 0, 0), mk(0, 0, -1));
     bool safe = false;
     WaveStats ws = {0, 0, 0, 0};
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
         if (COUNT) { outer_iters++; shade_lanes += (unsigned)__popcll(__ballot(hit)); }
         /* (A) lanes whose cast is complete pick their closest hit; a miss ends the path with the
          * sky term (shader.wgsl:128-132) */
-        float hit_t = PT_FAR;
+        float hit_t = P.far_distance;
         int32_t hit_id = PT_NONE;
         if (hit) {
             hit_t = sph_t; hit_id = sph_id;

@@ -74,7 +74,13 @@ def render_pixel_sharded(render_owned, all_reduce, first_frame, n_frames):
 
 class ShardedRenderer:
     """A Renderer whose accumulation buffer is a torch CUDA tensor so that
-    torch.distributed (backend "nccl" = RCCL) can reduce it in place."""
+    torch.distributed (backend "nccl" = RCCL) can reduce it.
+
+    pixels mode keeps TWO tensors: `owned`, bound to the library, holds the running mean of this
+    rank's own tiles and zeros elsewhere, and lives across calls, so a progressive render continues
+    (render(0, 4) then render(4, 4) == render(0, 8), like Renderer.render); `buffer` receives a copy
+    per call and is what the collective sums.  frames mode sums frame means and divides by their
+    number, which is the running mean only when the render starts at frame 0."""
 
     def __init__(self, renderer, rank, world_size, group=None, mode="pixels", collective="all_reduce"):
         """collective: "all_reduce" leaves the image on every rank, "reduce" on rank 0 only (what a
@@ -90,24 +96,37 @@ class ShardedRenderer:
         self.rank, self.world_size, self.group, self.mode = rank, world_size, group, mode
         renderer.set_pixel_shard(*((rank, world_size) if mode == "pixels" else (0, 1)))
         dev = torch.device("cuda", torch.cuda.current_device())
-        self.buffer = torch.zeros(renderer.height * renderer.width * 4, dtype=torch.float32, device=dev)
+        n = renderer.height * renderer.width * 4
+        self.buffer = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.owned = torch.zeros(n, dtype=torch.float32, device=dev) if mode == "pixels" else self.buffer
         torch.cuda.synchronize()
-        renderer.bind_accum(self.buffer.data_ptr())
+        renderer.bind_accum(self.owned.data_ptr())
+        self.last_timing = {}           # seconds of the last render(): kernels, collective
 
     def render(self, first_frame, n_frames):
+        import time
+
         import torch
         import torch.distributed as dist
 
-        self.r.reset_accum()          # zeroes the bound buffer on the library's stream, ordered before the render
+        if self.mode == "frames":
+            if first_frame != 0:
+                raise ValueError("frame sharding sums whole renders: first_frame must be 0 (use mode='pixels' to continue a render)")
+            self.r.reset_accum()      # zeroes the bound buffer on the library's stream, ordered before the render
+        t0 = time.perf_counter()
 
         def all_reduce():
             self.r.synchronize()                  # kernels run on the library's own stream
+            t1 = time.perf_counter()
+            if self.mode == "pixels":
+                self.buffer.copy_(self.owned)     # the collective must not touch the running means kept in `owned`
             if self.world_size > 1:
                 if self.collective == "reduce":
                     dist.reduce(self.buffer, dst=0, op=dist.ReduceOp.SUM, group=self.group)
                 else:
                     dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
-                torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            self.last_timing = {"render_s": t1 - t0, "collective_s": time.perf_counter() - t1}
 
         if self.mode == "pixels":
             render_pixel_sharded(lambda f, c: self.r.render_frames(f, c), all_reduce, first_frame, n_frames)

@@ -3,6 +3,7 @@ host-only entry points behave.  No GPU needed (no kernels are launched)."""
 import ctypes as C
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -25,11 +26,36 @@ def test_library_exports_every_declared_symbol(pkg):
     assert sorted(pkg.API_SYMBOLS) == syms
 
 
-def test_struct_layouts_match_header(pkg):
-    # pt_params: 5 x 4 bytes + 6 + 2 + 9 + 3 + 2 floats + 2 u32 -> 4-byte fields only
-    assert C.sizeof(pkg.PtParams) == 4 * (4 + 1 + 3 + 3 + 1 + 1 + 3 + 3 + 3 + 3 + 1 + 1 + 1 + 1)
-    assert C.sizeof(pkg.PtCounters) == 7 * 8
-    assert C.sizeof(pkg.PtTiming) == 2 * 8 + 3 * 8
+def test_header_is_plain_c99():
+    """The header is meant for bindgen / cgo / ctypes: it must compile as strict C99 on its own."""
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-x", "c",
+                    os.path.join(ROOT, "include", "pt_api.h")], check=True)
+
+
+def test_struct_layouts_match_header(pkg, tmp_path):
+    """sizeof / offsetof of every structure field as a C compiler sees the header == the ctypes mirror."""
+    structs = {"pt_params": pkg.PtParams, "pt_counters": pkg.PtCounters, "pt_timing": pkg.PtTiming}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "pt_api.h"', "int main(void) {"]
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, str(src)], check=True)
+    seen = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(seen[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(seen["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+    # the fields the reference fixes as WGSL constants (shader.wgsl:24-37, 48-54, 142, 283-286) are all there
+    names = [f for f, _ in pkg.PtParams._fields_]
+    for want in ("width", "height", "rays_per_pixel", "max_bounce_count", "bvh_max_depth", "fov_degrees", "far_distance",
+                 "tri_color", "tri_emission_color", "tri_emission_strength", "tri_smoothness", "sky_horizon", "sky_zenith",
+                 "ground", "sun_dir", "sun_intensity", "sun_focus", "use_environment_lighting"):
+        assert want in names
 
 
 def test_default_params_are_the_reference_constants(pkg):
@@ -39,6 +65,7 @@ def test_default_params_are_the_reference_constants(pkg):
     assert [round(x, 6) for x in p.tri_color] == [0.65, 0.65, 1.0] and round(p.tri_smoothness, 6) == 0.9
     assert list(p.sun_dir) == [0.0, np.float32(-0.4), 0.5] and p.sun_intensity == 3.0 and p.sun_focus == 200.0
     assert p.use_environment_lighting == 1 and p.flags == 0
+    assert p.far_distance == 1000000.0 and p.bvh_max_depth == 0          # shader.wgsl:142; 0 = depth of the node file
 
 
 def test_null_arguments_are_rejected_not_fatal(pkg):

@@ -42,7 +42,16 @@ def _worker(rank, world, port, n_frames, out_dir, mode):
         r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
         sh = ShardedRenderer(r, rank, world, mode=mode, collective="reduce" if mode == "pixels" else "all_reduce")
         sh.render(0, n_frames)
-        sh.render(0, n_frames)          # a second render must start from a clean buffer
+        if mode == "pixels":            # a second render restarts at frame 0 (weight 1) and is continued by a third call
+            sh.render(0, 2)
+            sh.render(2, n_frames - 2)
+        else:                           # a second render must start from a clean buffer
+            sh.render(0, n_frames)
+            try:
+                sh.render(1, 2)
+                raise AssertionError("frame sharding accepted first_frame != 0")
+            except ValueError:
+                pass
         img = sh.image().cpu().numpy()
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
     dist.barrier()

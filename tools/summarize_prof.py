@@ -14,7 +14,7 @@ def short(name):
     return m.group(1) if m else name
 
 
-def main(out):
+def main(out, all_dirs=False):
     print("== kernel trace ==")
     for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
         dur = defaultdict(list)
@@ -29,7 +29,7 @@ def main(out):
         print("-- rocprofv3 kernel_stats.csv --")
         print(open(f).read())
     print("== PMC (mean per dispatch, per kernel) ==")
-    for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
+    for d in sorted(glob.glob(os.path.join(out, "*" if all_dirs else "pmc_*"))):
         if not os.path.isdir(d):
             continue
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -38,6 +38,16 @@ def main(out):
                 for row in csv.DictReader(fh):
                     acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
             print("-- %s --" % os.path.basename(d))
+            if all_dirs and any(k == "walk" for k in acc):
+                # the gather microbenchmark launches one kernel several times with different arguments:
+                # list its dispatches one by one, in launch order
+                rows = defaultdict(dict)
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        rows[int(row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
+                for disp in sorted(rows):
+                    print("walk dispatch %-3d %s" % (disp, "  ".join("%s=%.4g" % kv for kv in sorted(rows[disp].items()))))
+                continue
             for k in acc:
                 vals = "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(acc[k].items()))
                 n = len(next(iter(acc[k].values())))
@@ -45,4 +55,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], len(sys.argv) > 2 and sys.argv[2] == "pmc_all")

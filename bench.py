@@ -70,9 +70,13 @@ def main():
     ap.add_argument("--config", type=int, default=4)
     ap.add_argument("--shard", choices=("pixels", "frames"), default="pixels",
                     help="N > 1: 8x8-pixel tiles (bit-identical image) or the frames of the render (sum + scale)")
+    ap.add_argument("--wide", action="store_true",
+                    help="PT_FLAG_WIDE_BVH: four-wide tree (not the reference's visit order; reported under its own workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting pass")
     args = ap.parse_args()
+    if args.wide:
+        args.no_count = True          # the work counters follow the reference's binary walk
 
     import numpy as np
     import torch
@@ -117,7 +121,7 @@ def main():
         r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
         return r
 
-    r = make_renderer()
+    r = make_renderer(pkg.PT_FLAG_WIDE_BVH if args.wide else 0)
     info = r.scene_info()
     # the image ends on rank 0
     sharded = ShardedRenderer(r, rank, world, mode=args.shard, collective="reduce") if world > 1 else None
@@ -179,7 +183,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": cfg["name"],
+                "workload": cfg["name"] + ("+wide4" if args.wide else ""),
                 "note": "dragon_800k is absent from the reference; SYNTHETIC STAND-IN = dragon_80k with every "
                         "triangle split 1->9, BVH from this repo's builder (max_depth %d)" % scenes.REGEN_MAX_DEPTH
                         if cfg["mesh"] == "dragon_800k_synth" else "",
@@ -211,7 +215,7 @@ def main():
         if os.path.exists(ppath):
             with open(ppath) as f:
                 pj = json.load(f)
-        if pj and pj.get("workload") == cfg["name"] and world == 1 and "path_kernel" in pj and timing["batches"]:
+        if pj and pj.get("workload") == cfg["name"] and world == 1 and "path_kernel" in pj and timing["batches"] and not args.wide:
             d = pj["path_kernel"]
             live_s = avg_ms * 1e-3
             roof["counter_pass"] = {"file": "profiles/path_kernel_pmc.json", "launch_ms_in_pass": d["trace_mean_ms"],

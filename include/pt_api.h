@@ -42,6 +42,14 @@ extern "C" {
 #define PT_FLAG_COUNT_WORK 2u  /* kernels also count box tests / triangle tests / ray casts
                                   (pt_get_counters); slower, for roofline accounting */
 
+#define PT_FLAG_WIDE_BVH 4u    /* traverse a four-wide tree folded from the node file at upload (children of inner
+                                  children pulled up): half as many dependent node visits.  Same boxes, same ray_box and
+                                  ray_triangle arithmetic, so every reported hit is a hit the shader's functions confirm
+                                  with the same distance, but the visit order is not the shader's: the closest-hit id can
+                                  differ on exact distance ties, and a triangle that the shader's walk loses because a
+                                  folded-away box rejects the ray can be found.  Not combinable with PT_FLAG_COUNT_WORK.
+                                  No counterpart in the reference (binary walk, shader.wgsl:169-235). */
+
 typedef struct pt_ctx pt_ctx;
 
 /*

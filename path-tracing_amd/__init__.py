@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
 PT_OK = 0
 PT_FLAG_EXACT_MATH = 1
 PT_FLAG_COUNT_WORK = 2
+PT_FLAG_WIDE_BVH = 4
 
 MISS_ID = -(2 ** 31)
 

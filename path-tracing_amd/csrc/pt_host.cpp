@@ -66,6 +66,9 @@ struct pt_ctx {
     PTTriRecord *d_tris = nullptr;
     float *d_spheres = nullptr;
     uint32_t *d_big = nullptr;
+    PTWideRecord *d_wide = nullptr;     /* PT_FLAG_WIDE_BVH: the four-wide tree */
+    uint32_t wide_count = 0, wide_root_ref = 0, wide_depth = 0;
+    int wide_stack_entries = 0;
     float4 *d_accum_own = nullptr;
     float4 *d_accum = nullptr;
     PTHitRecord *d_hits = nullptr;
@@ -261,6 +264,77 @@ void build_tri_records(const float *tris, uint32_t n, std::vector<PTTriRecord> &
     }
 }
 
+/* ---- binary records -> four-wide records (PT_FLAG_WIDE_BVH) ------------- */
+struct WideTree {
+    std::vector<PTWideRecord> nodes;
+    uint32_t root_ref = 0, depth = 0;
+};
+
+uint32_t float_bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+float bits_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* Folds the binary tree: a wide node is an inner node of the file whose inner children are replaced by
+ * their own two children (two to four children in all).  Boxes are copied, never merged or re-derived.
+ * A binary node reached over several links (legacy files have such links) is folded once. */
+void build_wide(const Repacked &rp, WideTree &out) {
+    if (rp.root_ref & PT_REF_LEAF) { out.root_ref = rp.root_ref; out.depth = 0; return; }
+    struct Child { float lo[3], hi[3]; uint32_t ref; };
+    auto children_of = [&](uint32_t rec, Child c[2]) {
+        const PTInnerRecord &r = rp.inner[rec];
+        c[0] = Child{{r.q[0].x, r.q[0].y, r.q[2].x}, {r.q[0].z, r.q[0].w, r.q[2].y}, float_bits(r.q[3].x)};
+        c[1] = Child{{r.q[1].x, r.q[1].y, r.q[2].z}, {r.q[1].z, r.q[1].w, r.q[2].w}, float_bits(r.q[3].y)};
+    };
+    std::vector<uint32_t> wide_of(rp.inner.size(), PT_REF_NONE), depth_of(rp.inner.size(), 0);
+    struct Frame { uint32_t rec, wide; Child ch[4]; int n, next; };
+    std::vector<Frame> st;
+    auto open = [&](uint32_t rec) {
+        Frame f;
+        f.rec = rec; f.wide = (uint32_t)out.nodes.size(); f.n = 0; f.next = 0;
+        Child two[2];
+        children_of(rec, two);
+        for (int k = 0; k < 2; k++) {
+            if (two[k].ref & PT_REF_LEAF) f.ch[f.n++] = two[k];
+            else { Child g[2]; children_of(two[k].ref, g); f.ch[f.n++] = g[0]; f.ch[f.n++] = g[1]; }
+        }
+        wide_of[rec] = f.wide;
+        out.nodes.emplace_back();
+        st.push_back(f);
+    };
+    open(rp.root_ref);
+    while (!st.empty()) {
+        Frame &f = st.back();
+        if (f.next < f.n) {
+            const uint32_t ref = f.ch[f.next++].ref;
+            if (!(ref & PT_REF_LEAF) && wide_of[ref] == PT_REF_NONE) open(ref);       /* invalidates f: re-read st.back() next round */
+            continue;
+        }
+        uint32_t d = 0;
+        PTWideRecord &w = out.nodes[f.wide];
+        uint32_t refs[4];
+        Child c[4];
+        for (int k = 0; k < 4; k++) {
+            c[k] = k < f.n ? f.ch[k] : f.ch[0];                /* an absent child repeats a real box and carries no reference */
+            refs[k] = PT_REF_NONE;
+            if (k < f.n) {
+                refs[k] = (c[k].ref & PT_REF_LEAF) ? c[k].ref : wide_of[c[k].ref];
+                if (!(c[k].ref & PT_REF_LEAF) && depth_of[c[k].ref] > d) d = depth_of[c[k].ref];
+            }
+        }
+        for (int pair = 0; pair < 2; pair++) {
+            const Child &a = c[2 * pair], &b = c[2 * pair + 1];
+            w.q[3 * pair + 0] = make_float4(a.lo[0], a.lo[1], a.hi[0], a.hi[1]);
+            w.q[3 * pair + 1] = make_float4(b.lo[0], b.lo[1], b.hi[0], b.hi[1]);
+            w.q[3 * pair + 2] = make_float4(a.lo[2], a.hi[2], b.lo[2], b.hi[2]);
+        }
+        w.q[6] = make_float4(bits_float(refs[0]), bits_float(refs[1]), bits_float(refs[2]), bits_float(refs[3]));
+        w.q[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        depth_of[f.rec] = d + 1;
+        st.pop_back();
+    }
+    out.root_ref = wide_of[rp.root_ref];
+    out.depth = depth_of[rp.root_ref];
+}
+
 int validate_params(const pt_params *p, std::string &why) {
     if (!p) { why = "params is NULL"; return PT_EINVAL; }
     if (p->width == 0 || p->height == 0 || p->width > 16384 || p->height > 16384) { why = "width/height must be in 1..16384"; return PT_EINVAL; }
@@ -272,6 +346,7 @@ int validate_params(const pt_params *p, std::string &why) {
     /* a missed box reports 999999999.0 (shader.wgsl:254) and must never pass `dst < far` */
     if (!(p->far_distance > 0.0f && p->far_distance <= 999999999.0f)) { why = "far_distance must be in (0, 999999999]"; return PT_EINVAL; }
     if (p->bvh_max_depth > 4096) { why = "bvh_max_depth too large"; return PT_EINVAL; }
+    if ((p->flags & PT_FLAG_WIDE_BVH) && (p->flags & PT_FLAG_COUNT_WORK)) { why = "PT_FLAG_WIDE_BVH and PT_FLAG_COUNT_WORK cannot be combined"; return PT_EINVAL; }
     return PT_OK;
 }
 
@@ -321,6 +396,11 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.sphere_count = c->sphere_count;
     k.root_ref = c->root_ref;
     k.stack_entries = (uint32_t)c->stack_entries;
+    if (c->d_wide) {
+        k.wide = c->d_wide; k.wide_bytes = c->wide_count * (uint32_t)sizeof(PTWideRecord);
+        k.root_ref = c->wide_root_ref;
+        k.stack_entries = (uint32_t)c->wide_stack_entries;
+    }
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
     k.leaf_min = c->leaf_min;
@@ -631,11 +711,29 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(rp.depth) + " exceeds the supported traversal stack");
     std::vector<PTTriRecord> trec;
     build_tri_records(triangles, triangle_count, trec);
+    WideTree wt;
+    int wide_need = 0;
+    const bool wide = (c->params.flags & PT_FLAG_WIDE_BVH) != 0;
+    if (wide) {
+        build_wide(rp, wt);
+        /* a visit keeps the nearest child and pushes up to three: three live entries per level */
+        wide_need = wt.depth > 0 ? 3 * (int)wt.depth : 1;
+        if (wide_need > pt_max_stack_entries())
+            return fail(c, PT_EINVAL, "four-wide tree of depth " + std::to_string(wt.depth) + " exceeds the supported traversal stack");
+    }
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->scene_loaded = false;
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_spill);
+    dev_free(c->d_wide);
+    c->wide_count = 0;
+    if (wide && !wt.nodes.empty()) {
+        HIP_TRY(c, hipMalloc(&c->d_wide, wt.nodes.size() * sizeof(PTWideRecord)));
+        HIP_TRY(c, hipMemcpy(c->d_wide, wt.nodes.data(), wt.nodes.size() * sizeof(PTWideRecord), hipMemcpyHostToDevice));
+        c->wide_count = (uint32_t)wt.nodes.size();
+    }
+    c->wide_root_ref = wt.root_ref; c->wide_depth = wt.depth; c->wide_stack_entries = wide_need;
     size_t n_inner = rp.inner.size() ? rp.inner.size() : 1;
     HIP_TRY(c, hipMalloc(&c->d_inner, n_inner * sizeof(PTInnerRecord)));
     if (!rp.inner.empty())
@@ -647,7 +745,7 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     if (sphere_count)
         HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, (size_t)sphere_count * 12 * sizeof(float), hipMemcpyHostToDevice));
     {   /* overflow area of the path kernel's traversal stacks (only trees deeper than its LDS part) */
-        size_t words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);
+        size_t words = (size_t)pt_spill_entries((uint32_t)(wide_need > need ? wide_need : need)) * pt_lane_stride(c->num_cus);
         HIP_TRY(c, hipMalloc(&c->d_spill, (words ? words : 1) * sizeof(uint32_t)));
     }
     if (rp.big.empty()) rp.big.assign(1, 0);
@@ -919,7 +1017,7 @@ void pt_destroy(pt_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (EventPair &ep : c->pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     for (EventPair &ep : c->free_events) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
-    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
+    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_wide);
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
     dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill);

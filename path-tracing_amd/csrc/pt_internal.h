@@ -12,6 +12,7 @@
  *                 count field 127 = "look the count up in big_leaf_count[first]" */
 #define PT_REF_LEAF 0x80000000u
 #define PT_REF_COUNT_ESCAPE 127u
+#define PT_REF_NONE 0xffffffffu     /* not a valid reference (a leaf of >= 127 triangles cannot start at triangle 2^24 - 1) */
 
 /* One inner node of the reference file, repacked so that ONE 64-byte record
  * holds everything a visit needs: both child boxes and both child references.
@@ -25,6 +26,12 @@
  * Box values are copied verbatim from the file, so ray_box sees the same
  * operands as the shader. */
 struct PTInnerRecord { float4 q[4]; };
+
+/* Four-wide node (PT_FLAG_WIDE_BVH): an inner node of the file with its inner children replaced by THEIR
+ * children, so one visit tests up to four boxes.  Two box blocks in the layout of PTInnerRecord (children 0, 1
+ * in q0-q2, children 2, 3 in q3-q5), q6 = the four child references as raw bits (0xffffffff = no such child;
+ * its box block then repeats child 0's box), q7 unused.  Box values are the file's, verbatim. */
+struct PTWideRecord { float4 q[8]; };
 
 /* One triangle in file order, with the ray-independent part of ray_triangle
  * (shader.wgsl:262-264) hoisted: a, ab = b - a, ac = c - a, n = cross(ab, ac),
@@ -91,6 +98,8 @@ struct PTKernelParams {
     uint32_t tris_bytes;           /* size of the triangle-record array (at most 2^24 x 48 bytes) */
     uint32_t inner_bytes;          /* size of the inner-record array (below 2^32: the upload refuses 2^26 or more inner records) */
     const PTTriRecord *tris;
+    const PTWideRecord *wide;      /* four-wide nodes, or null: the traversal follows the binary records */
+    uint32_t wide_bytes;
     const float *spheres;
     const uint32_t *big_leaf_count;
     float4 *accum;

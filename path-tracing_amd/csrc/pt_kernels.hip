@@ -241,7 +241,6 @@ __device__ __forceinline__ bool ray_sphere(V3 o, V3 d, const float *s, float &ds
  * same order.  stk points at this lane's column of the LDS stack (entries 64
  * dwords apart, so a wave's accesses never bank-conflict).
  */
-#define PT_REF_NONE 0xffffffffu     /* not a valid reference: see the encoding in pt_internal.h */
 
 struct Trav {
     uint32_t cur;      /* node to visit next, or PT_REF_NONE: pop one */
@@ -377,6 +376,51 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
     T.cur = (dst_near < T.best_t) ? ref_near : PT_REF_NONE;
 }
 
+/* compare-exchange of two (distance, reference) pairs: afterwards da <= db */
+__device__ __forceinline__ void order2(float &da, uint32_t &ra, float &db, uint32_t &rb) {
+    const bool swap = db < da;
+    const float dl = swap ? db : da, dh = swap ? da : db;
+    const uint32_t rl = swap ? rb : ra, rh = swap ? ra : rb;
+    da = dl; db = dh; ra = rl; rb = rh;
+}
+
+/*
+ * One visit of a four-wide node (PT_FLAG_WIDE_BVH; no counterpart in the shader, whose tree is binary,
+ * shader.wgsl:169-235).  The same ray_box arithmetic on the same box values, up to four boxes per visit;
+ * children are visited nearest first (five compare-exchanges), the others are pushed farthest first, each
+ * only if its entry distance is below the running best, as in the binary walk.  What differs from the
+ * binary walk: the boxes of the inner nodes that were folded away are never tested, and among equal
+ * distances the order is this function's, so a closest hit can differ where the shader's result hangs on
+ * an exact tie or on a box test that rejects a triangle the ray does hit.
+ */
+template <bool FAST, bool SPILL>
+__device__ __forceinline__ void wide_visit(const PTKernelParams &P, const WaveMem &M, Trav &T) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.wide, 0, (int)P.wide_bytes, 0x00020000);
+    const uint32_t off = T.cur * 128u;
+    u4_t w[7];
+#pragma unroll
+    for (int k = 0; k < 7; k++) w[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u * k, 0, 0);
+    float4 q[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        q[k] = make_float4(__uint_as_float(w[k].x), __uint_as_float(w[k].y), __uint_as_float(w[k].z), __uint_as_float(w[k].w));
+    float d0, d1, d2, d3;
+    ray_box2<FAST>(T.R, q[0], q[1], q[2], d0, d1);
+    ray_box2<FAST>(T.R, q[3], q[4], q[5], d2, d3);
+    uint32_t r0 = w[6].x, r1 = w[6].y, r2 = w[6].z, r3 = w[6].w;
+    if (r2 == PT_REF_NONE) d2 = PT_BOX_MISS;         /* a node has two to four children */
+    if (r3 == PT_REF_NONE) d3 = PT_BOX_MISS;
+    order2(d0, r0, d1, r1);
+    order2(d2, r2, d3, r3);
+    order2(d0, r0, d2, r2);
+    order2(d1, r1, d3, r3);
+    order2(d1, r1, d2, r2);
+    if (d3 < T.best_t) stack_push<SPILL>(M, T, r3);
+    if (d2 < T.best_t) stack_push<SPILL>(M, T, r2);
+    if (d1 < T.best_t) stack_push<SPILL>(M, T, r1);
+    T.cur = (d0 < T.best_t) ? r0 : PT_REF_NONE;
+}
+
 template <bool COUNT>
 __device__ __forceinline__ void leaf_visit(const PTKernelParams &P, Trav &T, Counters &cn) {
     const V3 o = ray_origin(T.R), d = ray_dir(T.R);
@@ -410,7 +454,7 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
  * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
-template <bool FAST, bool COUNT, bool SPILL>
+template <bool FAST, bool COUNT, bool SPILL, bool WIDE = false>
 __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, bool traversing,
                                                Trav &T, Counters &cn, WaveStats *ws = nullptr, int leaf_turn = -1) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
@@ -428,7 +472,8 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
         if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
     if (is_inner) {
-        inner_visit<FAST, COUNT, SPILL>(P, M, T, cn);
+        if (WIDE) wide_visit<FAST, SPILL>(P, M, T);
+        else inner_visit<FAST, COUNT, SPILL>(P, M, T, cn);
         done = trav_advance<SPILL>(M, T);
     }
     if (run_leaves) {
@@ -453,7 +498,7 @@ __device__ __forceinline__ void spheres_closest(const PTKernelParams &P, V3 o, V
 /* calculate_ray_collision, shader.wgsl:139-163, one whole cast for this lane: spheres in
  * index order, then the BVH (which does not see the sphere distance), strict `<`
  * everywhere.  `active` lanes take part; the division form is chosen per wave. */
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveMem &M, bool active, V3 o, V3 d,
                                             float &t_out, int32_t &id_out, Counters &cn) {
     float best = P.far_distance;
@@ -467,8 +512,8 @@ __device__ __forceinline__ void closest_hit(const PTKernelParams &P, const WaveM
     trav_begin(P, stack_bottom(M), T);
     bool traversing = active;
     while (__ballot(traversing)) {
-        bool done = fast ? trav_wave_step<true, COUNT, false>(P, M, traversing, T, cn)
-                         : trav_wave_step<false, COUNT, false>(P, M, traversing, T, cn);
+        bool done = fast ? trav_wave_step<true, COUNT, false, WIDE>(P, M, traversing, T, cn)
+                         : trav_wave_step<false, COUNT, false, WIDE>(P, M, traversing, T, cn);
         if (done) traversing = false;
     }
     if (active) {
@@ -594,7 +639,7 @@ __device__ __forceinline__ void flush_counters(const PTKernelParams &P, const Co
 }
 
 /* ======================= primary rays ======================= */
-template <bool EXACT, bool COUNT, bool AOV>
+template <bool EXACT, bool COUNT, bool AOV, bool WIDE = false>
 __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
@@ -621,7 +666,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     float t = P.far_distance;
     int32_t id = PT_NONE;
     if (valid) primary_ray(P, px, py, rd, pixel_index);
-    closest_hit<COUNT>(P, M, valid, ro, rd, t, id, cn);
+    closest_hit<COUNT, WIDE>(P, M, valid, ro, rd, t, id, cn);
     const uint32_t pixel = py * P.width + px;
     if (AOV) {
         if (valid) { P.out_ids[pixel] = id; P.out_dist[pixel] = t; }
@@ -685,7 +730,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_LEAF_PERIOD 3
 #endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
-template <bool EXACT, bool COUNT, bool SPILL>
+template <bool EXACT, bool COUNT, bool SPILL, bool WIDE = false>
 __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
@@ -833,8 +878,8 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
              * faster than deciding from lane counts in every step (2.98 -> 2.90 ms per frame). */
             for (int rep = 0; rep < PT_STEPS_PER_CHECK; rep++) {
                 const int turn = (rep % PT_LEAF_PERIOD) == PT_LEAF_PERIOD - 1 ? 1 : 0;
-                bool done = fast ? trav_wave_step<true, COUNT, SPILL>(P, M, trav, T, cn, &ws, turn)
-                                 : trav_wave_step<false, COUNT, SPILL>(P, M, trav, T, cn, &ws, turn);
+                bool done = fast ? trav_wave_step<true, COUNT, SPILL, WIDE>(P, M, trav, T, cn, &ws, turn)
+                                 : trav_wave_step<false, COUNT, SPILL, WIDE>(P, M, trav, T, cn, &ws, turn);
                 if (done) { trav = false; hit = true; }
             }
         }
@@ -1020,6 +1065,13 @@ hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, b
         grid = dim3((owned_per_row + PT_WAVES_PER_BLOCK - 1) / PT_WAVES_PER_BLOCK, tiles_y);
     }
     const size_t lds = block_lds_bytes(kp.stack_entries);
+    if (kp.wide) {            /* four-wide nodes: no work counters in this mode */
+        if (count) return hipErrorInvalidValue;
+        if (aov)        hipLaunchKernelGGL((primary_kernel<true, false, true, true>), grid, block, lds, st, kp);
+        else if (exact) hipLaunchKernelGGL((primary_kernel<true, false, false, true>), grid, block, lds, st, kp);
+        else            hipLaunchKernelGGL((primary_kernel<false, false, false, true>), grid, block, lds, st, kp);
+        return hipGetLastError();
+    }
     if (aov) {
         hipLaunchKernelGGL((primary_kernel<true, false, true>), grid, block, lds, st, kp);
     } else if (count) {
@@ -1036,6 +1088,11 @@ template <bool SPILL>
 static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool count, dim3 grid, size_t lds, uint32_t lds_entries,
                                  hipStream_t st) {
     dim3 block(PT_PATH_BLOCK);
+    if (kp.wide) {
+        if (exact) hipLaunchKernelGGL((path_kernel<true, false, SPILL, true>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, false, SPILL, true>), grid, block, lds, st, kp, lds_entries);
+        return;
+    }
     if (count) {
         if (exact) hipLaunchKernelGGL((path_kernel<true, true, SPILL>), grid, block, lds, st, kp, lds_entries);
         else       hipLaunchKernelGGL((path_kernel<false, true, SPILL>), grid, block, lds, st, kp, lds_entries);
@@ -1047,6 +1104,7 @@ static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool coun
 
 hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
     if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
+    if (kp.wide && count) return hipErrorInvalidValue;
     /* Trees of up to PT_PATH_LDS_ALL levels keep the whole stack in LDS (5 resident blocks x 30 KiB fit
      * the CU's 160 KiB); deeper ones keep PT_PATH_LDS_STACK entries there and the rest in global memory. */
     bool spill = kp.stack_entries > PT_PATH_LDS_ALL;

@@ -244,8 +244,9 @@ def main():
                 scale = d["trace_mean_ms"] / avg_ms
                 other["valu"] = {"frac_low": d["valu_busy_low"] * scale, "frac_high": d["valu_busy_high"] * scale,
                                  "lane_utilisation": d["valu_lane_utilisation"],
-                                 "note": "issue cycles / SIMD cycles: 2 per plain and 4 per packed-f32 instruction "
-                                         "(tools/ubench/valu_rate); low = all plain, high = SQ_ACTIVE_INST_VALU quad-cycles"}
+                                 "note": "issue cycles / SIMD cycles; high = SQ_ACTIVE_INST_VALU x 4 cycles (the counter's own busy "
+                                         "time), low = SQ_INSTS_VALU x 2 (as if every instruction were a 2-cycle v_fma/v_mul/v_add; "
+                                         "packed f32, min/max, compares and selects take 4: tools/ubench/valu_ops)"}
             roof["other_bounds"] = other
         elif world > 1:
             roof["note"] = "the counter pass describes the single-GPU launch shape; see per_rank for this run"

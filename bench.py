@@ -95,7 +95,10 @@ def main():
         local_rank = 0
         os.environ.setdefault("PT_SAMPLE_BUDGET_MB", "8192")      # N contexts share one GPU's memory
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # PT_BENCH_FORCE_GROUP=1 (started with torch.distributed.run --nproc-per-node 1): a process group of ONE rank
+    # over RCCL, so that everything the N > 1 path calls can be run on a one-GPU box
+    grouped = world > 1 or os.environ.get("PT_BENCH_FORCE_GROUP") == "1"
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -124,7 +127,7 @@ def main():
     r = make_renderer(pkg.PT_FLAG_WIDE_BVH if args.wide else 0)
     info = r.scene_info()
     # the image ends on rank 0
-    sharded = ShardedRenderer(r, rank, world, mode=args.shard, collective="reduce") if world > 1 else None
+    sharded = ShardedRenderer(r, rank, world, mode=args.shard, collective="reduce") if grouped else None
     phase = {"render_s": 0.0, "collective_s": 0.0}
 
     def step(timed=False):
@@ -139,7 +142,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -154,7 +157,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = r.timing()
     per_rank = None
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,7 +199,7 @@ def main():
                                     for k in ("primary_ms", "path_ms", "resolve_ms")},
             "kernel_launches_per_step": timing["batches"] / max(1, args.steps),
         }
-        if world > 1:
+        if grouped:
             result["per_rank"] = per_rank
             result["collective_ms_per_step"] = max(p["collective_ms_per_step"] for p in per_rank)
             result["predicted_efficiency"] = dict(PREDICTED_EFFICIENCY, note="pixel sharding, kernel time only, from "
@@ -328,7 +331,7 @@ def main():
     r.close()
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

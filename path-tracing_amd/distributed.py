@@ -120,7 +120,8 @@ class ShardedRenderer:
             t1 = time.perf_counter()
             if self.mode == "pixels":
                 self.buffer.copy_(self.owned)     # the collective must not touch the running means kept in `owned`
-            if self.world_size > 1:
+            # a process group of one rank still runs its collective (a rehearsal of the RCCL calls on one GPU)
+            if self.world_size > 1 or dist.is_initialized():
                 if self.collective == "reduce":
                     dist.reduce(self.buffer, dst=0, op=dist.ReduceOp.SUM, group=self.group)
                 else:

@@ -51,3 +51,19 @@ def test_headline_roofline_is_a_physical_fraction():
     assert 0 < ob["hbm"]["frac"] < 0.2 and 0 < ob["l2"]["frac"] < 0.5 and 0 < ob["valu"]["frac_low"] < ob["valu"]["frac_high"] <= 1
     # executed casts, not the reference's count: below 2 casts per sample on this scene
     assert r["executed_ray_casts_per_step"] < r["reference_ray_casts_per_step"]
+
+
+@pytest.mark.parametrize("shard", ["pixels", "frames"])
+def test_bench_under_the_launcher_with_a_one_rank_rccl_group(shard):
+    """What the driver does for N > 1 (torch.distributed.run, backend nccl, ShardedRenderer, max over ranks, per-rank
+    report), with the only group a one-GPU box allows: one rank (PT_BENCH_FORCE_GROUP=1)."""
+    env = dict(os.environ, PT_BENCH_FORCE_GROUP="1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--config", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", shard],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["path_ms_per_step"] > 0
+    assert d["collective_ms_per_step"] >= 0 and "predicted_efficiency" in d

@@ -58,6 +58,59 @@ def _worker(rank, world, port, n_frames, out_dir, mode):
     dist.destroy_process_group()
 
 
+def _rccl_worker(rank, port, n_frames, out_dir):
+    """One rank, backend nccl: the calls bench.py --gpus N makes (group creation bound to the device, reduce and
+    all_reduce on the tensor the library renders into, barrier, all_gather_object) on RCCL itself."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import ShardedRenderer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = pkg.default_params(width=96, height=54, rays_per_pixel=2, max_bounce_count=3, flags=pkg.PT_FLAG_EXACT_MATH)
+    for mode, collective in (("pixels", "reduce"), ("pixels", "all_reduce"), ("frames", "all_reduce")):
+        with pkg.Renderer(p, device=0) as r:
+            r.upload_scene(scenes.spheres_for("cfg1"), tris, bvh)
+            r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+            sh = ShardedRenderer(r, 0, 1, mode=mode, collective=collective)
+            sh.render(0, n_frames)
+            np.save(os.path.join(out_dir, "%s_%s.npy" % (mode, collective)), sh.image().cpu().numpy())
+    t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    gathered = [None]
+    dist.all_gather_object(gathered, {"rank": 0, "ms": float(t.item())})
+    assert gathered == [{"rank": 0, "ms": 1.5}]
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+
+
+def test_one_rank_process_group_on_rccl(tmp_path, oracle_shared, scenes):
+    """The box has one GPU, so RCCL can only be exercised with a group of one rank: same calls, same tensors."""
+    import torch.multiprocessing as mp
+    n_frames = 3
+    mp.spawn(_rccl_worker, args=(_free_port(), n_frames, str(tmp_path)), nprocs=1, join=True)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=96, height=54, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
+    for name in ("pixels_reduce", "pixels_all_reduce"):
+        img = np.load(tmp_path / (name + ".npy"))
+        assert np.array_equal(img[..., :3].view(np.uint32), mean[..., :3].view(np.uint32)), name
+    want = oracle_shared.render_frames_sum(p, sc, cam, rot, 0, n_frames, 1) * np.float32(1.0 / n_frames)
+    img = np.load(tmp_path / "frames_all_reduce.npy")
+    assert np.array_equal(img[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+
+
 def test_two_ranks_one_gpu_pixel_shards(tmp_path, oracle_shared, scenes):
     """Pixel sharding: every rank ends with the single-GPU running mean, bit for bit."""
     import torch.multiprocessing as mp

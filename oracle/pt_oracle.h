@@ -8,13 +8,16 @@
  * this code: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may use it, and only as the checker.
  *
- * PARITY UNPINNED for the shader path: the reference has no tests, no golden
- * vectors and cannot be executed in this environment (WGSL run through
- * wgpu/naga from a Rust binary; no Rust toolchain, no Vulkan).  The oracle is
- * therefore pinned only by (1) reading the shader line by line, (2) the
- * reference-produced scene files (teapot.bin / teapot_bvh.bin are reproduced
- * bit for bit by the builder restatement in bvh_build_oracle.c) and
- * (3) hand-computed known-answer tests in tests/.
+ * How it is pinned.  The reference has no tests and no golden vectors, and cannot be executed as its authors
+ * run it (WGSL through wgpu/naga from a Rust binary; no Rust toolchain, no Vulkan here).  Its shader TEXT can be
+ * executed: tests/golden/wgsl_interp.py interprets src/shaders/shader.wgsl statement by statement in strict
+ * binary32 arithmetic, and tests/golden/wgsl_golden.npz holds what the shader's own functions return (random_*,
+ * rotate_vector, get_environment_light, ray_box, ray_triangle, ray_sphere, calculate_ray_collision, trace, and
+ * fs_main over three whole frames of a 32 x 18 image of the teapot scene).  tests/test_wgsl_golden.py requires
+ * this oracle (and, on a GPU, the HIP kernels) to reproduce every one of those values bit for bit.  What that
+ * does NOT pin is the rounding of the built-ins WGSL leaves to the implementation (list below): interpreter,
+ * oracle and kernels share those choices, naga and a GPU driver may make others.  Also pinned by reference-produced
+ * data: teapot.bin / teapot_bvh.bin are reproduced bit for bit by the builder restatement in bvh_build_oracle.c.
  *
  * WGSL built-ins whose results the WGSL specification leaves
  * implementation-defined are fixed here as follows (the HIP kernels use the

@@ -2,8 +2,8 @@
 
 tests/golden/wgsl_golden.npz holds outputs of the reference's shader.wgsl, produced by executing its source text with
 the interpreter in tests/golden/wgsl_interp.py (tests/golden/make_wgsl_golden.py; only numbers are stored).  Every
-comparison here is bit for bit, with the portable log / cos / pow on both sides.  Where /root/reference exists the
-quick subset is generated again and must reproduce the committed file's values for the same inputs.
+comparison here is bit for bit, with the portable log / cos / pow on both sides.  Where /root/reference exists part of
+the file is computed again from the shader's text and must reproduce the committed values.
 """
 import os
 import sys
@@ -112,8 +112,8 @@ def test_whole_frames(G, oracle_shared, scenes):
 
 @pytest.mark.skipif(not os.path.exists(SHADER), reason="the reference is not on this machine")
 def test_the_committed_vectors_come_from_the_reference_shader(G, tmp_path):
-    """Runs the reference's shader text through the interpreter again (function vectors of the quick subset share their
-    first inputs with the committed file: same generator, same seed) and finds the committed outputs."""
+    """Runs the reference's shader text through the interpreter again on inputs of the committed file and finds the
+    committed outputs: the file is what the generator says it is."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     import make_wgsl_golden as mk
     import wgsl_interp as W
@@ -152,3 +152,38 @@ def test_gpu_frames_equal_the_shader(G, pkg, scenes):
             assert same(r.read_accum(4)[..., :3], G["frames_accum"][f]), "frame %d" % f
         r.render_frames(0, frames)                      # and as one batch
         assert same(r.read_accum(4)[..., :3], G["frames_accum"][frames - 1])
+
+
+@pytest.mark.gpu
+def test_gpu_functions_equal_the_shader(G, pkg, scenes):
+    """the device functions one by one (pt_probe_functions, pt_probe_intersections) against the shader's values"""
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    p = pkg.default_params(width=64, height=36, rays_per_pixel=1, max_bounce_count=1, flags=pkg.PT_FLAG_EXACT_MATH)
+    with pkg.Renderer(p) as r:
+        r.upload_scene(scenes.spheres_for(cfg["spheres"]), tris, bvh)
+        seeds = G["rng_seeds"]
+        f = r.probe_functions(seeds, np.tile(np.float32([0, 1, 0]), (len(seeds), 1)), G["rng_hemisphere_normal"])
+        assert same(f["random_value"], G["rng_value"]) and same(f["random_normal"], G["rng_normal"])
+        assert same(f["random_direction"], G["rng_direction"])
+        assert same(f["random_hemisphere_direction"], G["rng_hemisphere"])
+        dirs = G["env_dirs"]
+        f = r.probe_functions(np.ones(len(dirs), np.uint32), dirs, [0, 1, 0])
+        assert same(f["environment_light"], G["env_light"])
+        for v, a, want in zip(G["rot_vectors"], G["rot_angles"], G["rot_result"]):
+            r.set_camera([0, 0, 0], a)
+            assert same(r.probe_functions([1], [v], [0, 1, 0])["rotate_vector"][0], want)
+        n = len(G["box_result"])
+        rays = np.concatenate([G["box_origins"], G["box_dirs"]], axis=1)
+        x = r.probe_intersections(rays, G["box_bounds"], G["tri_vertices"][:n], G["sph_records"][:n, :4])
+        assert same(x["box"], G["box_result"])
+        ok = ~np.isnan(x["box_reciprocal"])             # rays and boxes that qualify for the reciprocal form
+        assert ok.sum() > n // 2 and same(x["box_reciprocal"][ok], G["box_result"][ok])
+        rays = np.concatenate([G["tri_origins"], G["tri_dirs"]], axis=1)
+        x = r.probe_intersections(rays, G["box_bounds"], G["tri_vertices"], G["sph_records"][:, :4])
+        hit = G["tri_hits"][:, 0] == 1.0
+        assert np.array_equal(x["tri_hit"], hit) and same(x["tri_distance"][hit], G["tri_hits"][hit, 1])
+        rays = np.concatenate([G["sph_origins"], G["sph_dirs"]], axis=1)
+        x = r.probe_intersections(rays, G["box_bounds"], G["tri_vertices"], G["sph_records"][:, :4])
+        hit = G["sph_hits"][:, 0] == 1.0
+        assert np.array_equal(x["sphere_hit"], hit) and same(x["sphere_distance"][hit], G["sph_hits"][hit, 1])

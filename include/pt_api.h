@@ -272,6 +272,20 @@ int pt_bvh_build(const float *triangles_in, uint32_t triangle_count, int max_dep
 void pt_free(void *p);
 
 /*
+ * The same builder on the GPU: same arguments, same output bytes as pt_bvh_build (and so as the
+ * reference tool, prepare_data/src/main.rs:14-136 + 179-220), computed by gfx950 kernels on device
+ * `device_ordinal`, one pass of the triangle array per tree level instead of 30 scans per node.  For scenes
+ * that are rebuilt while a program runs; the reference builds offline only.  *build_ms (may be NULL)
+ * receives the GPU time between the end of the upload and the start of the download.  Synchronous.
+ * Triangles with a non-finite coordinate or a negative zero are refused with PT_EINVAL (for those the
+ * reference's output depends on the order of its scans; pt_bvh_build handles them).
+ * pt_bvh_build_gpu_error(): message of the calling thread's last failed call.
+ */
+int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, uint32_t triangle_count, int max_depth,
+                     float *triangles_out, float **nodes_out, uint32_t *node_count, float *build_ms);
+const char *pt_bvh_build_gpu_error(void);
+
+/*
  * ASCII STL -> .bin converter, replaces prepare_data/data_formatter.js:9-18.
  * Every line containing "vertex" contributes the numbers that follow its first
  * "vertex " (split at single spaces, JavaScript Number() rules: an empty piece

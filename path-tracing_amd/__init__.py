@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_render_frames", "pt_render_frames_sum", "pt_scale_accum", "pt_read_accum", "pt_reset_accum",
     "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
-    "pt_last_error", "pt_bvh_build", "pt_free",
+    "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
     "pt_render_frames_static", "pt_static_scratch_bytes",
@@ -137,6 +137,9 @@ def load_library():
     L.pt_last_error.argtypes = [C.c_void_p]
     L.pt_last_error.restype = C.c_char_p
     L.pt_bvh_build.argtypes = [fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32)]
+    L.pt_bvh_build_gpu.argtypes = [C.c_int, fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32), fp]
+    L.pt_bvh_build_gpu_error.argtypes = []
+    L.pt_bvh_build_gpu_error.restype = C.c_char_p
     L.pt_free.argtypes = [C.c_void_p]
     L.pt_free.restype = None
     L.pt_stl_format.argtypes = [C.c_char_p, C.c_size_t, C.c_double, C.POINTER(fp), C.POINTER(C.c_uint64)]
@@ -186,6 +189,23 @@ def bvh_build(triangles, max_depth):
     nodes = np.ctypeslib.as_array(nodes_p, shape=(n.value, 9)).copy()
     L.pt_free(nodes_p)
     return out_tr, nodes
+
+
+def bvh_build_gpu(triangles, max_depth, device=0, return_ms=False):
+    """The same builder on the GPU (pt_bvh_build_gpu): same outputs as bvh_build, bit for bit.
+    With return_ms also the GPU time of the build in milliseconds (transfers excluded)."""
+    L = load_library()
+    tr = np.ascontiguousarray(np.asarray(triangles, dtype=np.float32).reshape(-1, 9))
+    out_tr = np.empty_like(tr)
+    nodes_p = C.POINTER(C.c_float)()
+    n = C.c_uint32()
+    ms = C.c_float()
+    rc = L.pt_bvh_build_gpu(int(device), _fp(tr), tr.shape[0], int(max_depth), _fp(out_tr), C.byref(nodes_p), C.byref(n), C.byref(ms))
+    if rc:
+        raise PtError(rc, (L.pt_bvh_build_gpu_error() or b"pt_bvh_build_gpu failed").decode())
+    nodes = np.ctypeslib.as_array(nodes_p, shape=(n.value, 9)).copy()
+    L.pt_free(nodes_p)
+    return (out_tr, nodes, float(ms.value)) if return_ms else (out_tr, nodes)
 
 
 def _key_array(keys):

@@ -1,0 +1,121 @@
+"""pt_bvh_build_gpu: the BVH builder on the GPU must write the bytes the host builder writes, and the host
+builder is pinned by the reference's own files (teapot.bin + teapot_bvh.bin, prepare_data/src/main.rs:176)."""
+import time
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+F = np.float32
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_builder_reproduces_reference_teapot_files(pkg, scenes):
+    tris, bvh = scenes.mesh("teapot")
+    out_tris, nodes = pkg.bvh_build_gpu(tris, 16)
+    assert nodes.shape == (30661, 9)
+    assert np.array_equal(bits(nodes), bits(bvh))
+    assert np.array_equal(bits(out_tris), bits(tris))
+
+
+@pytest.mark.parametrize("name,depth,shuffle", [
+    ("small_knight", 16, False), ("knight", 16, True), ("dragon_8k", 16, True), ("dragon_8k", 32, True),
+    ("dragon_80k", 32, False), ("dragon_80k", 32, True), ("teapot", 16, True), ("teapot", 5, False), ("teapot", 1, True),
+    ("teapot", 0, False)])
+def test_gpu_builder_equals_host_builder(pkg, scenes, name, depth, shuffle):
+    """Shuffled inputs exercise the partition's rotation of side B (main.rs:103-122); the committed files are
+    already in tree order, where every swap is a no-op."""
+    tris = scenes.load_bin(name + ".bin")
+    if shuffle:
+        tris = tris[np.random.default_rng(11).permutation(len(tris))]
+    t1, n1 = pkg.bvh_build(tris, depth)
+    t2, n2 = pkg.bvh_build_gpu(tris, depth)
+    assert n1.shape == n2.shape
+    assert np.array_equal(bits(n1), bits(n2))
+    assert np.array_equal(bits(t1), bits(t2))
+
+
+def test_gpu_builder_on_the_benchmark_mesh_and_its_time(pkg, scenes):
+    """784 170 triangles (configuration 4's stand-in), depth 32, from the unordered split of dragon_80k."""
+    tris = scenes.split_1_to_9(scenes.load_bin("dragon_80k.bin"))
+    t0 = time.perf_counter()
+    t1, n1 = pkg.bvh_build(tris, scenes.REGEN_MAX_DEPTH)
+    host_s = time.perf_counter() - t0
+    pkg.bvh_build_gpu(tris[:1000], 8)               # first call: module load
+    t0 = time.perf_counter()
+    t2, n2, ms = pkg.bvh_build_gpu(tris, scenes.REGEN_MAX_DEPTH, return_ms=True)
+    gpu_s = time.perf_counter() - t0
+    assert np.array_equal(bits(n1), bits(n2))
+    assert np.array_equal(bits(t1), bits(t2))
+    print("\nbuild of %d triangles -> %d nodes: host %.0f ms, GPU %.1f ms on the device, %.0f ms with transfers" % (
+        len(tris), len(n2), host_s * 1e3, ms, gpu_s * 1e3))
+    assert ms < host_s * 1e3
+
+
+def test_gpu_builder_random_soups(pkg):
+    """Random triangle soups with many equal centres and coordinates (ties in the plane tests, empty sides),
+    large and tiny extents, and long runs of one side (long chases in the permutation)."""
+    rng = np.random.default_rng(5)
+    for trial in range(12):
+        n = int(rng.integers(1, 5000))
+        scale = F(10.0) ** F(rng.integers(-6, 7))
+        if trial % 3 == 0:
+            pts = rng.integers(-4, 5, size=(n, 9)).astype(F) * scale       # lattice points: many ties
+        elif trial % 3 == 1:
+            pts = (rng.standard_normal((n, 9)) * scale).astype(F)
+        else:
+            c = np.sort(rng.standard_normal(n)).astype(F)[::-1]            # sorted the wrong way round along x
+            pts = (rng.standard_normal((n, 9)) * 0.01).astype(F)
+            pts[:, 0::3] += c[:, None]
+            pts = (pts * scale).astype(F)
+        pts[pts == 0] = 0.0                                                # no negative zeros
+        depth = int(rng.integers(0, 40))
+        t1, n1 = pkg.bvh_build(pts, depth)
+        t2, n2 = pkg.bvh_build_gpu(pts, depth)
+        assert n1.shape == n2.shape, (trial, n, depth)
+        assert np.array_equal(bits(n1), bits(n2)), (trial, n, depth)
+        assert np.array_equal(bits(t1), bits(t2)), (trial, n, depth)
+
+
+def test_gpu_builder_edge_cases(pkg):
+    one = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], F)
+    t, n = pkg.bvh_build_gpu(one, 16)
+    t1, n1 = pkg.bvh_build(one, 16)
+    assert np.array_equal(bits(n), bits(n1)) and np.array_equal(bits(t), bits(t1))
+    same = np.tile(one, (5, 1))
+    t, n = pkg.bvh_build_gpu(same, 16)
+    assert n.shape == (1, 9)
+    t, n = pkg.bvh_build_gpu(np.zeros((0, 9), F), 16)
+    t1, n1 = pkg.bvh_build(np.zeros((0, 9), F), 16)
+    assert np.array_equal(bits(n), bits(n1))
+    with pytest.raises(pkg.PtError):
+        pkg.bvh_build_gpu(one, -1)
+    bad = one.copy()
+    bad[0, 4] = -0.0
+    with pytest.raises(pkg.PtError, match="negative zero"):
+        pkg.bvh_build_gpu(bad, 16)
+    bad[0, 4] = np.nan
+    with pytest.raises(pkg.PtError, match="not finite"):
+        pkg.bvh_build_gpu(bad, 16)
+    with pytest.raises(pkg.PtError, match="no such device"):
+        pkg.bvh_build_gpu(one, 16, device=99)
+
+
+def test_scene_built_on_the_gpu_renders_like_the_oracle(pkg, oracle_shared, scenes):
+    """The renderer's input straight from the GPU builder: primary hits against the oracle on the same files."""
+    tris = scenes.load_bin("dragon_8k.bin")
+    out_tris, nodes = pkg.bvh_build_gpu(tris, 24)
+    W, H = 96, 54
+    cfg = scenes.config(2)
+    p = pkg.default_params(width=W, height=H, rays_per_pixel=1, max_bounce_count=2, flags=pkg.PT_FLAG_EXACT_MATH)
+    with pkg.Renderer(p) as r:
+        r.upload_scene(scenes.spheres_for(cfg["spheres"]), out_tris, nodes)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        ids, dist = r.primary_hits()
+    op = oracle_shared.default_params(width=W, height=H, rays_per_pixel=1, max_bounce_count=2)
+    sc = oracle_shared.scene(scenes.spheres_for(cfg["spheres"]), out_tris, nodes)
+    oid, odist = oracle_shared.primary_hits(op, sc, cfg["camera_position"], cfg["camera_rotation"])
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(bits(dist), bits(odist))
+    assert (ids >= 0).sum() > 500

@@ -48,6 +48,8 @@ constexpr int NP = 10;                    /* candidate planes per axis (num_test
 constexpr int NB = NP + 1;                /* buckets per axis */
 constexpr int BIN_WORDS = 3 * NB * 7;     /* per node: axis x bucket x (min xyz, max xyz, count) */
 constexpr uint32_t INACTIVE = 0xffffffffu;
+constexpr uint32_t SMALL = 8;             /* nodes of at most this many triangles skip the buckets: one thread scans them plane by plane */
+constexpr int SLOTS = 32;                 /* nodes a block of the bin kernel merges in LDS before it touches global memory */
 
 thread_local std::string g_error;
 
@@ -127,55 +129,60 @@ __device__ __forceinline__ void plane_positions(const GNode &nd, int axis, const
     for (int i = 0; i < NP; i++) pos[i] = start + (end - start) * st.t[i];
 }
 
-/* One thread per position of the triangle order.  A block whose positions all lie in one node (the
- * usual case while nodes are large) merges into LDS first and sends 231 atomics instead of 21 per
- * triangle. */
+/* One thread per position of the triangle order.  Nodes own contiguous ranges of positions and, within a
+ * level, their numbers rise with the positions, so the (at most SLOTS) nodes a block of 256 positions meets
+ * are merged in LDS first and only the touched bucket entries go to global memory as atomics; a node beyond
+ * the LDS slots is merged in global memory directly.  Nodes of at most SMALL triangles are left to
+ * small_decide_kernel. */
 __global__ __launch_bounds__(256) void bin_kernel(const GNode *nodes, uint32_t level_begin, const uint32_t *pos_node,
                                                   const uint32_t *order, const float *ctr, const float *tmn, const float *tmx,
                                                   uint32_t n, SplitT st, uint32_t *bins) {
-    __shared__ uint32_t s_bins[BIN_WORDS];
+    __shared__ uint32_t s_bins[SLOTS * BIN_WORDS];
+    __shared__ uint32_t s_base, s_top;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t first_p = blockIdx.x * blockDim.x;
-    const uint32_t last_p = min(first_p + blockDim.x, n) - 1u;
-    const uint32_t nd_first = pos_node[first_p], nd_last = pos_node[last_p];
-    /* a node owns one contiguous range of positions: the same node at both ends means the same node throughout */
-    const bool uniform = nd_first == nd_last && nd_first != INACTIVE;
-    if (uniform) {
-        for (uint32_t w = threadIdx.x; w < BIN_WORDS; w += blockDim.x) {
-            const uint32_t f = w % 7;
-            s_bins[w] = f < 3 ? KEY_POS_INF : (f < 6 ? KEY_NEG_INF : 0u);
-        }
-        __syncthreads();
+    if (threadIdx.x == 0) { s_base = INACTIVE; s_top = 0; }
+    __syncthreads();
+    uint32_t nid = p < n ? pos_node[p] : INACTIVE;
+    GNode nd;
+    if (nid != INACTIVE) {
+        nd = nodes[nid];
+        if (nd.count <= SMALL) nid = INACTIVE;
     }
-    if (p < n) {
-        const uint32_t nid = pos_node[p];
-        if (nid != INACTIVE) {
-            const GNode nd = nodes[nid];
-            const uint32_t t = order[p];
-            uint32_t klo[3], khi[3];
-            for (int k = 0; k < 3; k++) { klo[k] = fkey(tmn[3 * (size_t)t + k]); khi[k] = fkey(tmx[3 * (size_t)t + k]); }
-            uint32_t *dst = uniform ? s_bins : bins + (size_t)(nid - level_begin) * BIN_WORDS;
-            for (int axis = 0; axis < 3; axis++) {
-                float pos[NP];
-                plane_positions(nd, axis, st, pos);
-                const float c = ctr[3 * (size_t)t + axis];
-                int j = 0;
-                while (j < NP && !(c < pos[j])) j++;               /* first plane the centre lies below */
-                uint32_t *b = dst + (axis * NB + j) * 7;
-                for (int k = 0; k < 3; k++) { atomicMin(&b[k], klo[k]); atomicMax(&b[3 + k], khi[k]); }
-                atomicAdd(&b[6], 1u);
-            }
+    if (nid != INACTIVE) atomicMin(&s_base, nid);
+    __syncthreads();
+    const uint32_t base = s_base;
+    if (base == INACTIVE) return;                       /* nothing to merge in this block */
+    if (nid != INACTIVE && nid - base < (uint32_t)SLOTS) atomicMax(&s_top, nid - base + 1u);
+    __syncthreads();
+    const uint32_t used = s_top * BIN_WORDS;
+    for (uint32_t w = threadIdx.x; w < used; w += blockDim.x) {
+        const uint32_t f = w % 7;
+        s_bins[w] = f < 3 ? KEY_POS_INF : (f < 6 ? KEY_NEG_INF : 0u);
+    }
+    __syncthreads();
+    if (nid != INACTIVE) {
+        const uint32_t t = order[p];
+        uint32_t klo[3], khi[3];
+        for (int k = 0; k < 3; k++) { klo[k] = fkey(tmn[3 * (size_t)t + k]); khi[k] = fkey(tmx[3 * (size_t)t + k]); }
+        uint32_t *dst = nid - base < (uint32_t)SLOTS ? s_bins + (nid - base) * BIN_WORDS : bins + (size_t)(nid - level_begin) * BIN_WORDS;
+        for (int axis = 0; axis < 3; axis++) {
+            float pos[NP];
+            plane_positions(nd, axis, st, pos);
+            const float c = ctr[3 * (size_t)t + axis];
+            int j = 0;
+            while (j < NP && !(c < pos[j])) j++;               /* first plane the centre lies below */
+            uint32_t *b = dst + (axis * NB + j) * 7;
+            for (int k = 0; k < 3; k++) { atomicMin(&b[k], klo[k]); atomicMax(&b[3 + k], khi[k]); }
+            atomicAdd(&b[6], 1u);
         }
     }
-    if (uniform) {
-        __syncthreads();
-        uint32_t *g = bins + (size_t)(nd_first - level_begin) * BIN_WORDS;
-        for (uint32_t w = threadIdx.x; w < BIN_WORDS; w += blockDim.x) {
-            const uint32_t f = w % 7, v = s_bins[w];
-            if (f < 3) { if (v != KEY_POS_INF) atomicMin(&g[w], v); }
-            else if (f < 6) { if (v != KEY_NEG_INF) atomicMax(&g[w], v); }
-            else if (v) atomicAdd(&g[w], v);
-        }
+    __syncthreads();
+    uint32_t *g = bins + (size_t)(base - level_begin) * BIN_WORDS;
+    for (uint32_t w = threadIdx.x; w < used; w += blockDim.x) {
+        const uint32_t f = w % 7, v = s_bins[w];
+        if (f < 3) { if (v != KEY_POS_INF) atomicMin(&g[w], v); }
+        else if (f < 6) { if (v != KEY_NEG_INF) atomicMax(&g[w], v); }
+        else if (v) atomicAdd(&g[w], v);
     }
 }
 
@@ -189,12 +196,33 @@ __device__ __forceinline__ void side_merge(Side &s, const uint32_t *b) {
     s.n += b[6];
 }
 
-/* choose_split + the stop rule, main.rs:33-57 and :88-96.  One thread per node of the level. */
+/* the stop rule and the split that follows from the best candidate, main.rs:88-96 and :124 */
+__device__ __forceinline__ void finish_decision(GNode &nd, float best_cost, int best_axis, int best_i, float best_pos,
+                                                const Side &sa, const Side &sb, float *cb, uint32_t *has_children, uint32_t *error_flag) {
+    const float parent_cost = node_cost(nd.mn, nd.mx, (float)nd.count);
+    nd.child = 0; nd.permuted = 0; nd.n_a = 0; nd.axis = 0; nd.pos = 0.0f;
+    uint32_t both = 0;
+    if (!(best_cost >= parent_cost)) {
+        if (best_i < 0) {
+            /* no candidate was better than +inf and the parent cost is NaN: the reference then partitions at
+             * axis 0, position 0, which is none of the candidate planes */
+            atomicOr(error_flag, 1u);
+        } else {
+            nd.permuted = 1; nd.axis = (uint32_t)best_axis; nd.pos = best_pos; nd.n_a = sa.n;
+            both = (sa.n > 0 && sb.n > 0) ? 1u : 0u;           /* main.rs:124 */
+            for (int k = 0; k < 3; k++) { cb[k] = sa.mn[k]; cb[3 + k] = sa.mx[k]; cb[6 + k] = sb.mn[k]; cb[9 + k] = sb.mx[k]; }
+        }
+    }
+    *has_children = both;
+}
+
+/* choose_split + the stop rule, main.rs:33-57 and :88-96, from the buckets.  One thread per node of the level. */
 __global__ __launch_bounds__(64) void decide_kernel(GNode *nodes, uint32_t level_begin, uint32_t level_count, const uint32_t *bins,
                                                     SplitT st, float *child_boxes, uint32_t *has_children, uint32_t *error_flag) {
     const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= level_count) return;
     GNode nd = nodes[level_begin + a];
+    if (nd.count <= SMALL) return;                      /* small_decide_kernel's */
     const uint32_t *nb = bins + (size_t)a * BIN_WORDS;
     float best_cost = INFINITY;
     int best_axis = 0, best_i = -1;
@@ -212,27 +240,64 @@ __global__ __launch_bounds__(64) void decide_kernel(GNode *nodes, uint32_t level
         for (int i = 0; i < NP; i++)
             if (cost[i] < best_cost) { best_cost = cost[i]; best_pos = pos[i]; best_axis = axis; best_i = i; }
     }
-    const float parent_cost = node_cost(nd.mn, nd.mx, (float)nd.count);
-    nd.child = 0; nd.permuted = 0; nd.n_a = 0; nd.axis = 0; nd.pos = 0.0f;
-    uint32_t both = 0;
-    if (!(best_cost >= parent_cost)) {
-        if (best_i < 0) {
-            /* no candidate was better than +inf and the parent cost is NaN: the reference then partitions at
-             * axis 0, position 0, which is none of the binned planes */
-            atomicOr(error_flag, 1u);
+    Side sa, sb;
+    side_reset(sa); side_reset(sb);
+    if (best_i >= 0) {
+        const uint32_t *ab = nb + best_axis * NB * 7;
+        for (int i = 0; i <= best_i; i++) side_merge(sa, ab + i * 7);
+        for (int i = NP; i > best_i; i--) side_merge(sb, ab + i * 7);
+    }
+    finish_decision(nd, best_cost, best_axis, best_i, best_pos, sa, sb, child_boxes + 12 * (size_t)a, has_children + a, error_flag);
+    nodes[level_begin + a] = nd;
+}
+
+/* The same decision for nodes of at most SMALL triangles, the way the reference takes it: one scan of the
+ * node's triangles per candidate plane (main.rs:59-78), one thread per node, triangles held in registers. */
+__global__ __launch_bounds__(64) void small_decide_kernel(GNode *nodes, uint32_t level_begin, uint32_t level_count, const uint32_t *order,
+                                                          const float *ctr, const float *tmn, const float *tmx, SplitT st,
+                                                          float *child_boxes, uint32_t *has_children, uint32_t *error_flag) {
+    const uint32_t a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= level_count) return;
+    GNode nd = nodes[level_begin + a];
+    if (nd.count > SMALL) return;
+    float c[SMALL][3], lo[SMALL][3], hi[SMALL][3];
+#pragma unroll
+    for (uint32_t k = 0; k < SMALL; k++) {
+        if (k < nd.count) {
+            const uint32_t t = order[nd.start + k];
+            for (int x = 0; x < 3; x++) { c[k][x] = ctr[3 * (size_t)t + x]; lo[k][x] = tmn[3 * (size_t)t + x]; hi[k][x] = tmx[3 * (size_t)t + x]; }
         } else {
-            Side sa, sb;
-            side_reset(sa); side_reset(sb);
-            const uint32_t *ab = nb + best_axis * NB * 7;
-            for (int i = 0; i <= best_i; i++) side_merge(sa, ab + i * 7);
-            for (int i = NP; i > best_i; i--) side_merge(sb, ab + i * 7);
-            nd.permuted = 1; nd.axis = (uint32_t)best_axis; nd.pos = best_pos; nd.n_a = sa.n;
-            both = (sa.n > 0 && sb.n > 0) ? 1u : 0u;           /* main.rs:124 */
-            float *cb = child_boxes + 12 * (size_t)a;
-            for (int k = 0; k < 3; k++) { cb[k] = sa.mn[k]; cb[3 + k] = sa.mx[k]; cb[6 + k] = sb.mn[k]; cb[9 + k] = sb.mx[k]; }
+            for (int x = 0; x < 3; x++) { c[k][x] = 0.0f; lo[k][x] = INFINITY; hi[k][x] = -INFINITY; }
         }
     }
-    has_children[a] = both;
+    float best_cost = INFINITY;
+    int best_axis = 0, best_i = -1;
+    float best_pos = 0.0f;
+    Side best_a, best_b;
+    side_reset(best_a); side_reset(best_b);
+#pragma unroll
+    for (int axis = 0; axis < 3; axis++) {
+        float pos[NP];
+        plane_positions(nd, axis, st, pos);
+        for (int i = 0; i < NP; i++) {
+            Side sa, sb;
+            side_reset(sa); side_reset(sb);
+#pragma unroll
+            for (uint32_t k = 0; k < SMALL; k++) {
+                if (k < nd.count) {
+                    const bool in_a = c[k][axis] < pos[i];
+                    for (int x = 0; x < 3; x++) {
+                        if (in_a) { sa.mn[x] = fmin2(lo[k][x], sa.mn[x]); sa.mx[x] = fmax2(hi[k][x], sa.mx[x]); }
+                        else      { sb.mn[x] = fmin2(lo[k][x], sb.mn[x]); sb.mx[x] = fmax2(hi[k][x], sb.mx[x]); }
+                    }
+                    if (in_a) sa.n++; else sb.n++;
+                }
+            }
+            const float cost = node_cost(sa.mn, sa.mx, (float)sa.n) + node_cost(sb.mn, sb.mx, (float)sb.n);
+            if (cost < best_cost) { best_cost = cost; best_pos = pos[i]; best_axis = axis; best_i = i; best_a = sa; best_b = sb; }
+        }
+    }
+    finish_decision(nd, best_cost, best_axis, best_i, best_pos, best_a, best_b, child_boxes + 12 * (size_t)a, has_children + a, error_flag);
     nodes[level_begin + a] = nd;
 }
 
@@ -517,6 +582,8 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
         hipLaunchKernelGGL(bins_init_kernel, grid_for(words, 256), dim3(256), 0, stream, d_bins, words);
         hipLaunchKernelGGL(bin_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, lb, d_pos_node, d_order, d_ctr, d_tmn, d_tmx, n, st, d_bins);
         hipLaunchKernelGGL(decide_kernel, grid_for(lc, 64), dim3(64), 0, stream, d_nodes, lb, lc, d_bins, st, d_child_boxes, d_has, d_small + 7);
+        hipLaunchKernelGGL(small_decide_kernel, grid_for(lc, 64), dim3(64), 0, stream, d_nodes, lb, lc, d_order, d_ctr, d_tmn, d_tmx, st, d_child_boxes,
+                           d_has, d_small + 7);
         hipLaunchKernelGGL(flag_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_order, d_ctr, n, d_flag);
         exclusive_scan(d_flag, n, d_scan, d_sums, d_small + 6, stream);
         hipLaunchKernelGGL(a_index_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, n, d_a_index);

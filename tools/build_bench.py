@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Times pt_bvh_build_gpu against pt_bvh_build on a mesh of the benchmark configurations (needs a GPU).
+usage: tools/build_bench.py [mesh] [repeats]     mesh: dragon_800k_synth (default), dragon_80k, teapot, ..."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import __graft_entry__ as entry
+pkg = entry.load_package()
+from path_tracing_amd import scenes
+
+mesh = sys.argv[1] if len(sys.argv) > 1 else "dragon_800k_synth"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if mesh == "dragon_800k_synth":
+    tris = scenes.split_1_to_9(scenes.load_bin("dragon_80k.bin"))
+else:
+    tris = scenes.load_bin(mesh + ".bin")
+depth = scenes.REGEN_MAX_DEPTH
+t0 = time.perf_counter()
+ht, hn = pkg.bvh_build(tris, depth)
+host_ms = (time.perf_counter() - t0) * 1e3
+pkg.bvh_build_gpu(tris[:64], 4)
+dev, wall = [], []
+for _ in range(reps):
+    t0 = time.perf_counter()
+    gt, gn, ms = pkg.bvh_build_gpu(tris, depth, return_ms=True)
+    wall.append((time.perf_counter() - t0) * 1e3)
+    dev.append(ms)
+same = np.array_equal(hn.view(np.uint32), gn.view(np.uint32)) and np.array_equal(ht.view(np.uint32), gt.view(np.uint32))
+print("%s: %d triangles -> %d nodes, max_depth %d; host %.0f ms; GPU %.2f ms on the device (best of %d; with transfers %.1f ms); "
+      "outputs identical: %s" % (mesh, len(tris), len(gn), depth, host_ms, min(dev), reps, min(wall), same))

@@ -119,3 +119,20 @@ def test_scene_built_on_the_gpu_renders_like_the_oracle(pkg, oracle_shared, scen
     assert np.array_equal(ids, oid)
     assert np.array_equal(bits(dist), bits(odist))
     assert (ids >= 0).sum() > 500
+
+
+def test_pt_prepare_with_the_gpu_builder_reproduces_the_reference_teapot_pair(tmp_path):
+    """pt_prepare --bin --gpu: the Rust tool's job (prepare_data/src/main.rs:176, depth 16) done on the GPU."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    obj = os.path.join(ROOT, "assets", "objects")
+    tool = os.path.join(ROOT, "path-tracing_amd", "pt_prepare")
+    shutil.copy(os.path.join(obj, "teapot.bin"), tmp_path / "t.bin")
+    res = subprocess.run([tool, "--bin", str(tmp_path / "t.bin"), str(tmp_path / "t_bvh.bin"), "--gpu"],
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    assert "built on GPU 0" in res.stdout
+    assert open(tmp_path / "t.bin", "rb").read() == open(os.path.join(obj, "teapot.bin"), "rb").read()
+    assert open(tmp_path / "t_bvh.bin", "rb").read() == open(os.path.join(obj, "teapot_bvh.bin"), "rb").read()

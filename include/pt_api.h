@@ -135,6 +135,18 @@ int pt_upload_scene(pt_ctx *ctx, const float *spheres, uint32_t sphere_count,
 int pt_load_scene_files(pt_ctx *ctx, const char *triangles_bin, const char *bvh_bin,
                         const float *spheres, uint32_t sphere_count);
 
+/* Refit: the triangles of the uploaded scene moved (same count, same order), the tree keeps its shape.
+ * No counterpart in the reference, whose tree is built offline (prepare_data/src/main.rs); the result is
+ * what pt_upload_scene would hold for `triangles` and the uploaded node file with every node's box replaced
+ * by the tight bounds of the triangles in its range (the rule the builder's boxes follow, main.rs:16-20,
+ * :108-117), bit for bit, computed on the GPU in the resident records: triangles: triangle_count x 9 f32 as in
+ * pt_upload_scene.  Spheres, camera and accumulation buffer are untouched (reset the accumulation as after a
+ * camera move).  PT_EINVAL for a node file in which a reachable inner node does not cover exactly the ranges
+ * of its two children, A then B (files of the builders here and of the reference's current builder do; its
+ * legacy dragon_8k file does not), and for non-finite coordinates; PT_ESTATE with PT_FLAG_WIDE_BVH.
+ * Synchronous. */
+int pt_refit_scene(pt_ctx *ctx, const float *triangles);
+
 /* Replaces the camera position / rotation buffers, bindings 3 and 4, written
  * every frame by State::render (src/main.rs:455-464).  Rotation in degrees,
  * applied as in rotate_vector (shader.wgsl:327-348). */

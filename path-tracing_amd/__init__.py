@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_render_frames", "pt_render_frames_sum", "pt_scale_accum", "pt_read_accum", "pt_reset_accum",
     "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
-    "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error",
+    "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error", "pt_refit_scene",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
     "pt_render_frames_static", "pt_static_scratch_bytes",
@@ -107,6 +107,7 @@ def load_library():
     L.pt_default_params.argtypes = [C.POINTER(PtParams)]
     L.pt_create.argtypes = [C.c_int, C.POINTER(PtParams), C.POINTER(C.c_void_p)]
     L.pt_upload_scene.argtypes = [C.c_void_p, fp, C.c_uint32, fp, C.c_uint32, fp, C.c_uint32]
+    L.pt_refit_scene.argtypes = [C.c_void_p, fp]
     L.pt_load_scene_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, fp, C.c_uint32]
     L.pt_set_camera.argtypes = [C.c_void_p, fp, fp]
     L.pt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
@@ -313,16 +314,28 @@ class Renderer:
         bv = np.ascontiguousarray(np.asarray(bvh, dtype=np.float32).reshape(-1, 9))
         self._check(self._L.pt_upload_scene(self._ctx, _fp(sp), sp.shape[0], _fp(tr), tr.shape[0],
                                             _fp(bv), bv.shape[0]))
+        self.triangle_count = tr.shape[0]
 
     def load_scene_files(self, triangles_bin, bvh_bin, spheres=()):
         sp = np.ascontiguousarray(np.asarray(spheres, dtype=np.float32).reshape(-1, 12))
         self._check(self._L.pt_load_scene_files(self._ctx, os.fsencode(triangles_bin), os.fsencode(bvh_bin),
                                                 _fp(sp), sp.shape[0]))
+        self.triangle_count = os.path.getsize(triangles_bin) // 36
 
     def scene_info(self):
         d, i, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self._L.pt_scene_info(self._ctx, C.byref(d), C.byref(i), C.byref(l)))
         return {"bvh_depth": d.value, "inner_nodes": i.value, "leaves": l.value}
+
+    def refit_scene(self, triangles, reset=True):
+        """pt_refit_scene: the triangles moved, the tree keeps its shape; the node boxes and triangle records
+        are recomputed on the GPU.  Restarts the accumulation like a camera move unless reset is False."""
+        tr = np.ascontiguousarray(np.asarray(triangles, dtype=np.float32).reshape(-1, 9))
+        if tr.shape[0] != getattr(self, "triangle_count", -1):
+            raise ValueError("refit_scene needs the %d triangles of the uploaded scene, got %d" % (getattr(self, "triangle_count", 0), tr.shape[0]))
+        self._check(self._L.pt_refit_scene(self._ctx, _fp(tr)))
+        if reset:
+            self.frame_count = 0
 
     # -- camera (main.rs:45-115, 455-464) ---------------------------------
     def set_camera(self, position, rotation_degrees, reset=True):

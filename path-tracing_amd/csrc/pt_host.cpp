@@ -89,6 +89,15 @@ struct pt_ctx {
     int32_t *d_ids = nullptr;
     float *d_dist = nullptr;
 
+    /* refit (pt_refit_scene): inner records ordered by height, where each height starts, a staging buffer for
+     * the new triangles (allocated by the first refit), a flag word */
+    uint32_t *d_refit_order = nullptr;
+    std::vector<uint32_t> refit_level_begin;
+    float *d_tri9 = nullptr;
+    uint32_t *d_refit_flag = nullptr;
+    bool refit_ok = false;
+    std::string refit_why;
+
     bool scene_loaded = false;
     uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
     uint32_t root_ref = 0, depth = 0, inner_count = 0, leaf_count = 0;
@@ -133,6 +142,9 @@ struct Repacked {
     std::vector<uint32_t> big;     /* per-triangle count table, only when a leaf has >= 127 triangles */
     uint32_t root_ref = 0, depth = 0, leaves = 0;
     bool tame_bounds = true;       /* see pt_exact_div.h */
+    std::vector<uint32_t> height;  /* per inner record: 1 + the larger height of its inner children (leaf children count 0) */
+    bool refit_ok = true;          /* every reachable inner node's triangle range is the ranges of its children, A then B */
+    std::string refit_why;
 };
 
 bool finite_nonneg_int(float f) { return f >= 0.0f && f <= 16777216.0f && f == std::floor(f); }
@@ -238,6 +250,19 @@ bool repack_nodes(const float *bvh, uint32_t node_count, uint32_t tri_count, Rep
         memcpy(&fa, &ra, 4); memcpy(&fb, &rb, 4);
         r.q[3] = make_float4(fa, fb, 0.0f, 0.0f);
         height[f.node] = 1 + (ha > hb ? ha : hb);
+        if (out.height.size() < out.inner.size()) out.height.resize(out.inner.size(), 0);
+        out.height[f.rec] = height[f.node];
+        if (out.refit_ok) {
+            /* what a refit relies on: the node's range is child A's followed by child B's, none of them empty */
+            const float *nn = bvh + 9 * (size_t)f.node;
+            const bool ints = finite_nonneg_int(nn[6]) && finite_nonneg_int(nn[7]) && finite_nonneg_int(na[6]) && finite_nonneg_int(na[7]) &&
+                              finite_nonneg_int(nb[6]) && finite_nonneg_int(nb[7]);
+            if (!ints || na[7] < 1.0f || nb[7] < 1.0f || na[6] != nn[6] || nb[6] != na[6] + na[7] || na[7] + nb[7] != nn[7] ||
+                (double)nn[6] + (double)nn[7] > (double)tri_count) {
+                out.refit_ok = false;
+                out.refit_why = "node " + std::to_string(f.node) + " of the file does not cover exactly the triangle ranges of its children";
+            }
+        }
         rec_of[f.node] = f.rec;
         st.pop_back();
     }
@@ -726,7 +751,8 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->scene_loaded = false;
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_spill);
-    dev_free(c->d_wide);
+    dev_free(c->d_wide); dev_free(c->d_refit_order); dev_free(c->d_tri9);
+    c->refit_ok = false; c->refit_level_begin.clear();
     c->wide_count = 0;
     if (wide && !wt.nodes.empty()) {
         HIP_TRY(c, hipMalloc(&c->d_wide, wt.nodes.size() * sizeof(PTWideRecord)));
@@ -756,7 +782,49 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     c->inner_count = (uint32_t)rp.inner.size(); c->leaf_count = rp.leaves;
     c->stack_entries = need;
     c->fast_div = rp.tame_bounds && getenv("PT_NO_FAST_DIV") == nullptr;
+    c->refit_ok = rp.refit_ok; c->refit_why = rp.refit_why;
+    if (c->refit_ok && !rp.inner.empty()) {
+        /* counting sort of the records by height: a refit walks the heights upwards */
+        uint32_t top = 0;
+        for (uint32_t h : rp.height) if (h > top) top = h;
+        std::vector<uint32_t> begin(top + 2, 0), order(rp.inner.size());
+        for (uint32_t h : rp.height) begin[h + 1]++;
+        for (uint32_t h = 1; h < top + 2; h++) begin[h] += begin[h - 1];
+        std::vector<uint32_t> fill(begin.begin(), begin.end() - 1);
+        for (uint32_t r = 0; r < rp.inner.size(); r++) order[fill[rp.height[r]]++] = r;
+        HIP_TRY(c, hipMalloc(&c->d_refit_order, order.size() * sizeof(uint32_t)));
+        HIP_TRY(c, hipMemcpy(c->d_refit_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->refit_level_begin = begin;
+    }
     c->scene_loaded = true;
+    return PT_OK;
+}
+
+int pt_refit_scene(pt_ctx *c, const float *triangles) {
+    if (!c) return PT_EINVAL;
+    if (!c->scene_loaded) return fail(c, PT_ESTATE, "no scene uploaded");
+    if (c->tri_count && !triangles) return fail(c, PT_EINVAL, "triangles is NULL");
+    if (c->d_wide) return fail(c, PT_ESTATE, "pt_refit_scene does not update the four-wide tree (PT_FLAG_WIDE_BVH)");
+    if (!c->refit_ok) return fail(c, PT_EINVAL, "this node file cannot be refitted: " + c->refit_why);
+    const size_t n_floats = 9 * (size_t)c->tri_count;
+    for (size_t i = 0; i < n_floats; i++) {
+        uint32_t u;
+        memcpy(&u, triangles + i, 4);
+        if ((u & 0x7f800000u) == 0x7f800000u) return fail(c, PT_EINVAL, "a triangle coordinate is not finite");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->d_tri9) HIP_TRY(c, hipMalloc(&c->d_tri9, (n_floats ? n_floats : 1) * sizeof(float)));
+    if (!c->d_refit_flag) HIP_TRY(c, hipMalloc(&c->d_refit_flag, sizeof(uint32_t)));
+    HIP_TRY(c, hipMemcpyAsync(c->d_tri9, triangles, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_refit_flag, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, pt_launch_refit_tris(c->d_tri9, c->tri_count, c->d_tris, c->stream));
+    for (size_t h = 1; h + 1 < c->refit_level_begin.size(); h++)
+        HIP_TRY(c, pt_launch_refit_level(c->d_inner, c->d_refit_order, c->refit_level_begin[h],
+                                         c->refit_level_begin[h + 1] - c->refit_level_begin[h], c->d_tri9, c->d_big, c->d_refit_flag, c->stream));
+    uint32_t not_tame = 0;
+    HIP_TRY(c, hipMemcpyAsync(&not_tame, c->d_refit_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->fast_div = !not_tame && getenv("PT_NO_FAST_DIV") == nullptr;
     return PT_OK;
 }
 
@@ -1021,6 +1089,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
     dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill);
+    dev_free(c->d_refit_order); dev_free(c->d_tri9); dev_free(c->d_refit_flag);
     if (c->h_hit_count) (void)hipHostFree(c->h_hit_count);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -126,6 +126,11 @@ hipError_t pt_launch_probe_intersections(const float *rays, const float *boxes, 
                                          uint32_t n, float *out, hipStream_t stream);
 hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t *seeds, const float *dirs,
                            const float normal[3], uint32_t n, float *out, hipStream_t stream);
+/* refit, implemented in pt_refit.hip: triangle records from 9-float triangles; the child boxes of the inner
+ * records order[begin .. begin + count) (all of one height) from their children */
+hipError_t pt_launch_refit_tris(const float *tri9, uint32_t n, PTTriRecord *out, hipStream_t stream);
+hipError_t pt_launch_refit_level(PTInnerRecord *inner, const uint32_t *order, uint32_t begin, uint32_t count, const float *tri9,
+                                 const uint32_t *big, uint32_t *not_tame, hipStream_t stream);
 int pt_max_stack_entries(void);
 uint32_t pt_lane_stride(int num_cus);   /* upper bound of the path kernel's grid size in lanes */
 uint32_t pt_spill_entries(uint32_t stack_entries);

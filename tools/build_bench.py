@@ -28,3 +28,19 @@ for _ in range(reps):
 same = np.array_equal(hn.view(np.uint32), gn.view(np.uint32)) and np.array_equal(ht.view(np.uint32), gt.view(np.uint32))
 print("%s: %d triangles -> %d nodes, max_depth %d; host %.0f ms; GPU %.2f ms on the device (best of %d; with transfers %.1f ms); "
       "outputs identical: %s" % (mesh, len(tris), len(gn), depth, host_ms, min(dev), reps, min(wall), same))
+
+# refit of the resident scene (pt_refit_scene): same triangles moved a little, wall time of the call
+# (host check of the coordinates, 28 MB upload, kernels, one synchronisation)
+p = pkg.default_params(width=64, height=36, rays_per_pixel=1)
+with pkg.Renderer(p) as r:
+    t0 = time.perf_counter()
+    r.upload_scene([], gt, gn)
+    up_ms = (time.perf_counter() - t0) * 1e3
+    moved = (gt * np.float32(1.01)).astype(np.float32)
+    r.refit_scene(moved)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r.refit_scene(moved)
+        ts.append((time.perf_counter() - t0) * 1e3)
+print("pt_refit_scene: %.2f ms per call (best of %d); pt_upload_scene of the same scene (host repack + copies): %.0f ms" % (min(ts), reps, up_ms))

@@ -352,6 +352,29 @@ def test_config4_all_sixteen_frames_on_a_pixel_lattice(pkg, scenes, oracle_share
     assert np.array_equal(bits(got), bits(want))
 
 
+@pytest.mark.parametrize("n", [4, 2, 3, 5])
+def test_whole_image_at_full_size(pkg, scenes, oracle_shared, n):
+    """Every pixel of the benchmark images, not a lattice.  Configuration 4 (what bench.py times): 1920x1080, 16 rays
+    per pixel, 8 bounces, 784 k triangles; 2, 3: the smaller dragons; 5: 3840x2160, 16 spheres, 12 bounces.  Frames 0
+    and 1 as a running mean and frame 13 (wrapped seed term, shader.wgsl:121) on its own, the whole buffers bit-exact
+    against the oracle in exact-math mode (configuration 4: 2 M pixels x 16 samples x 3 frames, 7 s with 16 threads)."""
+    cfg, r, op, sc = _setup(pkg, scenes, oracle_shared, n, flags=pkg.PT_FLAG_EXACT_MATH)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+    W, H = cfg["width"], cfg["height"]
+    with r:
+        r.render_frames(0, 2)
+        img01 = r.read_accum(4)
+        r.reset_accum()
+        r.render_frames_sum(13, 1, 1)
+        img13 = r.read_accum(4)
+    want01 = oracle_shared.render_frames(op, sc, cam, rot, 0, 2, nthreads=16)
+    want13 = oracle_shared.render_frames_sum(op, sc, cam, rot, 13, 1, 1, nthreads=16)
+    assert want01.shape[:2] == (H, W)
+    assert (want01[..., :3].sum(axis=-1) > 0).mean() > 0.5
+    assert np.array_equal(bits(img01[..., :3]), bits(want01[..., :3]))
+    assert np.array_equal(bits(img13[..., :3]), bits(want13[..., :3]))
+
+
 @pytest.mark.parametrize("exact", [True, False])
 def test_seed_zero_direction_is_nan_and_renders_like_the_oracle(pkg, scenes, oracle, oracle_shared, exact):
     """random_value(0) = 0 -> log(0) = -inf -> random_normal = inf -> normalize(inf, inf, inf) = NaN

@@ -17,7 +17,7 @@ static void sim_visit(int is_leaf, int depth, float best);
 
 typedef struct { uint8_t leaf; uint8_t depth; uint8_t improved; } visit_t;     /* improved: this leaf lowered the best distance */
 typedef struct { uint32_t first_visit, n_visits; } cast_t;
-typedef struct { uint32_t first_cast, n_casts; } path_t;
+typedef struct { uint32_t first_cast, n_casts, pixel; } path_t;
 
 static visit_t *g_visits; static size_t g_nvis, g_capvis;
 static cast_t *g_casts; static size_t g_ncast, g_capcast;
@@ -50,7 +50,7 @@ int sim_profile(const orc_params *p, const orc_scene *s, const float cam[3], con
             uint32_t seed = pixel_index + smp * 248135u;
             orc_v3 ro = from3(o), rd = from3(d);
             if (g_npath == g_cappath) { g_cappath = g_cappath ? g_cappath * 2 : 4096; g_paths = realloc(g_paths, g_cappath * sizeof(path_t)); }
-            path_t *P = &g_paths[g_npath++]; P->first_cast = (uint32_t)g_ncast; P->n_casts = 0;
+            path_t *P = &g_paths[g_npath++]; P->first_cast = (uint32_t)g_ncast; P->n_casts = 0; P->pixel = y * p->width + x;
             for (uint32_t i = 0; i <= p->max_bounce_count; i++) {
                 orc_hit hit;
                 float o3[3] = {ro.x, ro.y, ro.z}, d3[3] = {rd.x, rd.y, rd.z};
@@ -74,6 +74,16 @@ int sim_profile(const orc_params *p, const orc_scene *s, const float cam[3], con
         }
     }
     return (int)g_npath;
+}
+
+/* per path: pixel, bounce casts, node visits of all its casts */
+void sim_paths(uint32_t *pixel, uint32_t *casts, uint32_t *visits) {
+    for (size_t i = 0; i < g_npath; i++) {
+        pixel[i] = g_paths[i].pixel; casts[i] = g_paths[i].n_casts;
+        uint32_t v = 0;
+        for (uint32_t c = 0; c < g_paths[i].n_casts; c++) v += g_casts[g_paths[i].first_cast + c].n_visits;
+        visits[i] = v;
+    }
 }
 
 void sim_sizes(uint64_t out[4]) {

@@ -147,6 +147,16 @@ int pt_load_scene_files(pt_ctx *ctx, const char *triangles_bin, const char *bvh_
  * Synchronous. */
 int pt_refit_scene(pt_ctx *ctx, const float *triangles);
 
+/* Rebuild: new triangles (any count >= 1, any order), a new tree, everything on the GPU: the tree of
+ * pt_bvh_build_gpu(triangles, max_depth) and the records pt_upload_scene would make from its two files, without
+ * the files ever existing on the host.  No counterpart in the reference (offline builder, prepare_data/src/main.rs).
+ * Afterwards the context holds exactly what pt_upload_scene(ctx, <the spheres it had>, triangles_out, ..., nodes_out,
+ * ...) of that build would have left, so triangle ids in pt_primary_hits are positions in the builder's triangle
+ * order.  Spheres, camera and accumulation buffer are untouched; a context without a scene gets one without spheres.
+ * *build_ms (may be NULL): GPU time from the end of the upload of the coordinates.  Same refusals as
+ * pt_bvh_build_gpu; PT_ESTATE with PT_FLAG_WIDE_BVH.  Synchronous. */
+int pt_rebuild_scene(pt_ctx *ctx, const float *triangles, uint32_t triangle_count, int max_depth, float *build_ms);
+
 /* Replaces the camera position / rotation buffers, bindings 3 and 4, written
  * every frame by State::render (src/main.rs:455-464).  Rotation in degrees,
  * applied as in rotate_vector (shader.wgsl:327-348). */
@@ -296,6 +306,9 @@ void pt_free(void *p);
 int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, uint32_t triangle_count, int max_depth,
                      float *triangles_out, float **nodes_out, uint32_t *node_count, float *build_ms);
 const char *pt_bvh_build_gpu_error(void);
+/* pt_bvh_build_gpu and pt_rebuild_scene keep their scratch buffers (up to 8 GiB per process) for the next build, so
+ * that a program that rebuilds every frame does not pay hipMalloc / hipFree each time; this returns them to the driver. */
+void pt_bvh_build_gpu_release_cache(void);
 
 /*
  * ASCII STL -> .bin converter, replaces prepare_data/data_formatter.js:9-18.

@@ -64,7 +64,7 @@ API_SYMBOLS = [
     "pt_render_frames", "pt_render_frames_sum", "pt_scale_accum", "pt_read_accum", "pt_reset_accum",
     "pt_bind_accum", "pt_accum_device_ptr", "pt_primary_hits", "pt_synchronize", "pt_get_counters",
     "pt_reset_counters", "pt_get_debug_stats", "pt_get_timing", "pt_reset_timing", "pt_scene_info", "pt_destroy",
-    "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error", "pt_refit_scene",
+    "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error", "pt_bvh_build_gpu_release_cache", "pt_refit_scene", "pt_rebuild_scene",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
     "pt_render_frames_static", "pt_static_scratch_bytes",
@@ -108,6 +108,7 @@ def load_library():
     L.pt_create.argtypes = [C.c_int, C.POINTER(PtParams), C.POINTER(C.c_void_p)]
     L.pt_upload_scene.argtypes = [C.c_void_p, fp, C.c_uint32, fp, C.c_uint32, fp, C.c_uint32]
     L.pt_refit_scene.argtypes = [C.c_void_p, fp]
+    L.pt_rebuild_scene.argtypes = [C.c_void_p, fp, C.c_uint32, C.c_int, fp]
     L.pt_load_scene_files.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, fp, C.c_uint32]
     L.pt_set_camera.argtypes = [C.c_void_p, fp, fp]
     L.pt_render_frames.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
@@ -140,6 +141,8 @@ def load_library():
     L.pt_bvh_build.argtypes = [fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32)]
     L.pt_bvh_build_gpu.argtypes = [C.c_int, fp, C.c_uint32, C.c_int, fp, C.POINTER(fp), C.POINTER(C.c_uint32), fp]
     L.pt_bvh_build_gpu_error.argtypes = []
+    L.pt_bvh_build_gpu_release_cache.argtypes = []
+    L.pt_bvh_build_gpu_release_cache.restype = None
     L.pt_bvh_build_gpu_error.restype = C.c_char_p
     L.pt_free.argtypes = [C.c_void_p]
     L.pt_free.restype = None
@@ -326,6 +329,16 @@ class Renderer:
         d, i, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self._L.pt_scene_info(self._ctx, C.byref(d), C.byref(i), C.byref(l)))
         return {"bvh_depth": d.value, "inner_nodes": i.value, "leaves": l.value}
+
+    def rebuild_scene(self, triangles, max_depth, reset=True):
+        """pt_rebuild_scene: a new tree for new triangles, built and packed on the GPU.  Returns the GPU time in ms."""
+        tr = np.ascontiguousarray(np.asarray(triangles, dtype=np.float32).reshape(-1, 9))
+        ms = C.c_float()
+        self._check(self._L.pt_rebuild_scene(self._ctx, _fp(tr), tr.shape[0], int(max_depth), C.byref(ms)))
+        self.triangle_count = tr.shape[0]
+        if reset:
+            self.frame_count = 0
+        return float(ms.value)
 
     def refit_scene(self, triangles, reset=True):
         """pt_refit_scene: the triangles moved, the tree keeps its shape; the node boxes and triangle records

@@ -30,6 +30,8 @@
  * zeros, NaN poisons comparisons), which atomics do not reproduce; pt_bvh_build handles them.
  */
 #include "../../include/pt_api.h"
+#include "pt_scene_build.h"
+#include "pt_exact_div.h"
 
 #include <hip/hip_runtime.h>
 
@@ -37,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -456,17 +459,61 @@ __global__ __launch_bounds__(256) void write_tris_kernel(const float *tri9, cons
     out[w] = tri9[9 * (size_t)order[w / 9u] + w % 9u];
 }
 
+/* Scratch memory of the builds.  hipMalloc and hipFree of some twenty buffers cost more than the build itself
+ * (about 15 ms against 9 ms for 784 k triangles), so freed scratch blocks are kept per device and handed out again
+ * to a later build that asks for about the same size: a program that rebuilds every frame allocates once.  At most
+ * CACHE_LIMIT bytes are kept; pt_bvh_build_gpu_release_cache() returns them to the driver. */
+struct CachedBlock { int device; size_t bytes; void *ptr; };
+std::mutex g_cache_mutex;
+std::vector<CachedBlock> g_cache;
+size_t g_cache_bytes = 0;
+constexpr size_t CACHE_LIMIT = (size_t)8 << 30;
+
+hipError_t scratch_alloc(int device, size_t bytes, void **out, size_t *got) {
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        size_t best = g_cache.size();
+        for (size_t i = 0; i < g_cache.size(); i++)
+            if (g_cache[i].device == device && g_cache[i].bytes >= bytes && g_cache[i].bytes <= bytes + bytes / 2 + 4096 &&
+                (best == g_cache.size() || g_cache[i].bytes < g_cache[best].bytes)) best = i;
+        if (best != g_cache.size()) {
+            *out = g_cache[best].ptr; *got = g_cache[best].bytes;
+            g_cache_bytes -= g_cache[best].bytes;
+            g_cache.erase(g_cache.begin() + (long)best);
+            return hipSuccess;
+        }
+    }
+    *got = bytes;
+    return hipMalloc(out, bytes);
+}
+
+void scratch_free(int device, void *p, size_t bytes) {
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        if (g_cache_bytes + bytes <= CACHE_LIMIT && g_cache.size() < 256) {
+            g_cache.push_back(CachedBlock{device, bytes, p});
+            g_cache_bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
 struct DeviceBuffers {
-    std::vector<void *> ptrs;
-    ~DeviceBuffers() { for (void *p : ptrs) (void)hipFree(p); }
+    int device = 0;
+    struct Held { void *ptr; size_t bytes; };
+    std::vector<Held> held;
+    ~DeviceBuffers() { for (const Held &h : held) scratch_free(device, h.ptr, h.bytes); }
     template <typename T> hipError_t alloc(T *&p, size_t count) {
         void *v = nullptr;
-        hipError_t e = hipMalloc(&v, (count ? count : 1) * sizeof(T));
-        if (e == hipSuccess) { ptrs.push_back(v); p = (T *)v; }
+        size_t got = 0;
+        hipError_t e = scratch_alloc(device, (count ? count : 1) * sizeof(T), &v, &got);
+        if (e == hipSuccess) { held.push_back(Held{v, got}); p = (T *)v; }
         return e;
     }
     void release(void *p) {
-        for (size_t i = 0; i < ptrs.size(); i++) if (ptrs[i] == p) { (void)hipFree(p); ptrs.erase(ptrs.begin() + (long)i); return; }
+        for (size_t i = 0; i < held.size(); i++)
+            if (held[i].ptr == p) { scratch_free(device, p, held[i].bytes); held.erase(held.begin() + (long)i); return; }
     }
 };
 
@@ -490,15 +537,22 @@ void exclusive_scan(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *d_s
 
 }  // namespace
 
+
 extern "C" const char *pt_bvh_build_gpu_error(void) { return g_error.c_str(); }
 
-extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, uint32_t triangle_count, int max_depth,
-                                float *triangles_out, float **nodes_out, uint32_t *node_count, float *build_ms) {
-    g_error.clear();
-    if (!nodes_out || !node_count || max_depth < 0 || max_depth > 1024) return fail(PT_EINVAL, "bad argument");
-    if (triangle_count && (!triangles_in || !triangles_out)) return fail(PT_EINVAL, "bad argument");
-    if (triangle_count > (1u << 24)) return fail(PT_EINVAL, "more than 2^24 triangles (indices are stored as f32 in the node file)");
-    const uint32_t n = triangle_count;
+extern "C" void pt_bvh_build_gpu_release_cache(void) {
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    for (const CachedBlock &b : g_cache) {
+        if (hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.ptr);
+    }
+    g_cache.clear();
+    g_cache_bytes = 0;
+}
+
+namespace {
+
+int check_triangles(const float *triangles_in, uint32_t n) {
+    if (n > (1u << 24)) return fail(PT_EINVAL, "more than 2^24 triangles (indices are stored as f32 in the node file)");
     for (size_t i = 0; i < 9 * (size_t)n; i++) {
         uint32_t u;
         memcpy(&u, triangles_in + i, 4);
@@ -506,16 +560,10 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
             return fail(PT_EINVAL, "a coordinate is not finite or is a negative zero: the reference's result then depends on the order "
                                    "of its scans; use pt_bvh_build");
     }
-    if (build_ms) *build_ms = 0.0f;
-    if (n == 0) {
-        /* the reference writes the empty root: bounds (+inf, -inf), no triangles (main.rs:16-20) */
-        float *out = (float *)malloc(9 * sizeof(float));
-        if (!out) return fail(PT_ENOMEM, "out of memory");
-        const float inf = std::numeric_limits<float>::infinity();
-        out[0] = out[1] = out[2] = inf; out[3] = out[4] = out[5] = -inf; out[6] = out[7] = out[8] = 0.0f;
-        *nodes_out = out; *node_count = 1;
-        return PT_OK;
-    }
+    return PT_OK;
+}
+
+int select_device(int device_ordinal) {
     int dev_count = 0;
     GB_TRY(hipGetDeviceCount(&dev_count));
     if (device_ordinal < 0 || device_ordinal >= dev_count) return fail(PT_EINVAL, "no such device");
@@ -524,12 +572,27 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
     GB_TRY(hipGetDeviceProperties(&prop, device_ordinal));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(PT_EHIP, std::string("this library is built for gfx950 (MI355X); the device is ") + prop.gcnArchName);
+    return PT_OK;
+}
 
+/* what grow_tree leaves in device memory (owned by the DeviceBuffers it was given) */
+struct Tree {
+    float *d_tri9 = nullptr;               /* the triangles as given */
+    GNode *d_nodes = nullptr;              /* nodes in creation order */
+    uint32_t *d_order = nullptr;           /* order[p] = input index of the triangle at position p of the output */
+    uint32_t *d_splits = nullptr;          /* split nodes in each node's subtree */
+    uint32_t *d_rank = nullptr;            /* of a split node: its number among the split nodes in the reference's recursion order */
+    uint32_t *d_file_index = nullptr;      /* the node's index in the node file */
+    std::vector<uint32_t> level_begin, level_count;
+    uint32_t total_nodes = 0;
+};
+
+/* With the device current and n >= 1: uploads the triangles, records ev0, grows the tree level by level and
+ * numbers the nodes.  Everything is enqueued on `stream`; the last level's read-back has synchronised it. */
+int grow_tree(const float *triangles_in, uint32_t n, int max_depth, hipStream_t stream, hipEvent_t ev0, DeviceBuffers &db, Tree &t) {
     SplitT st;
     for (int i = 0; i < NP; i++) st.t[i] = (float)(i + 1) / (float)(NP + 1);
 
-    DeviceBuffers db;
-    hipStream_t stream = nullptr;          /* the default stream: the call is synchronous */
     const size_t max_nodes = 2 * (size_t)n + 1;
     float *d_tri9 = nullptr, *d_ctr = nullptr, *d_tmn = nullptr, *d_tmx = nullptr, *d_child_boxes = nullptr;
     uint32_t *d_order = nullptr, *d_order_next = nullptr, *d_pos_node = nullptr, *d_flag = nullptr, *d_scan = nullptr, *d_a_index = nullptr;
@@ -554,11 +617,7 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
     GB_TRY(db.alloc(d_child_boxes, 12 * (size_t)n));
     size_t bins_nodes = 0;
 
-    GB_TRY(hipMemcpy(d_tri9, triangles_in, 9 * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
-    hipEvent_t ev0, ev1;
-    GB_TRY(hipEventCreate(&ev0));
-    GB_TRY(hipEventCreate(&ev1));
-    struct EventGuard { hipEvent_t a, b; ~EventGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } guard{ev0, ev1};
+    GB_TRY(hipMemcpyAsync(d_tri9, triangles_in, 9 * (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream));
     GB_TRY(hipEventRecord(ev0, stream));
 
     const uint32_t small_init[8] = {KEY_POS_INF, KEY_POS_INF, KEY_POS_INF, KEY_NEG_INF, KEY_NEG_INF, KEY_NEG_INF, 0u, 0u};
@@ -566,7 +625,8 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
     hipLaunchKernelGGL(prep_kernel, grid_for(n, 256), dim3(256), 0, stream, d_tri9, n, d_ctr, d_tmn, d_tmx, d_order, d_pos_node, d_small);
     hipLaunchKernelGGL(root_kernel, dim3(1), dim3(1), 0, stream, d_small, n, d_nodes);
 
-    std::vector<uint32_t> level_begin{0}, level_count{1};
+    std::vector<uint32_t> &level_begin = t.level_begin, &level_count = t.level_count;
+    level_begin.assign(1, 0); level_count.assign(1, 1);
     uint32_t total_nodes = 1;
     for (int depth = 0; depth < max_depth; depth++) {           /* main.rs:88: a node at max_depth is not split */
         const uint32_t lb = level_begin.back(), lc = level_count.back();
@@ -604,24 +664,197 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
 
     /* reference order of the nodes */
     uint32_t *d_splits = nullptr, *d_rank = nullptr, *d_file_index = nullptr;
-    float *d_nodes_out = nullptr, *d_tris_out = nullptr;
     GB_TRY(db.alloc(d_splits, total_nodes));
     GB_TRY(db.alloc(d_rank, total_nodes));
     GB_TRY(db.alloc(d_file_index, total_nodes));
-    GB_TRY(db.alloc(d_nodes_out, 9 * (size_t)total_nodes));
-    GB_TRY(db.alloc(d_tris_out, 9 * (size_t)n));
     GB_TRY(hipMemsetAsync(d_rank, 0, sizeof(uint32_t), stream));
     GB_TRY(hipMemsetAsync(d_file_index, 0, sizeof(uint32_t), stream));
     for (size_t l = level_begin.size(); l-- > 0;)
         hipLaunchKernelGGL(subtree_kernel, grid_for(level_count[l], 256), dim3(256), 0, stream, d_nodes, level_begin[l], level_count[l], d_splits);
     for (size_t l = 0; l < level_begin.size(); l++)
         hipLaunchKernelGGL(number_kernel, grid_for(level_count[l], 256), dim3(256), 0, stream, d_nodes, level_begin[l], level_count[l], d_splits, d_rank, d_file_index);
-    hipLaunchKernelGGL(write_nodes_kernel, grid_for(total_nodes, 256), dim3(256), 0, stream, d_nodes, total_nodes, d_file_index, d_nodes_out);
-    hipLaunchKernelGGL(write_tris_kernel, grid_for(9 * (size_t)n, 256), dim3(256), 0, stream, d_tri9, d_order, n, d_tris_out);
-    GB_TRY(hipEventRecord(ev1, stream));
+    GB_TRY(hipGetLastError());
+    t.d_tri9 = d_tri9; t.d_nodes = d_nodes; t.d_order = d_order;
+    t.d_splits = d_splits; t.d_rank = d_rank; t.d_file_index = d_file_index; t.total_nodes = total_nodes;
+    return PT_OK;
+}
+
+struct EventPairGuard {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t create() { hipError_t e = hipEventCreate(&a); return e != hipSuccess ? e : hipEventCreate(&b); }
+    ~EventPairGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+/* ---- the renderer's records straight from the tree (pt_gpu_build_resident) ---- */
+__device__ __forceinline__ uint32_t leaf_ref_of(const GNode &nd, uint32_t *big) {
+    if (nd.count >= PT_REF_COUNT_ESCAPE) {
+        big[nd.start] = nd.count;
+        return PT_REF_LEAF | (PT_REF_COUNT_ESCAPE << 24) | nd.start;
+    }
+    return PT_REF_LEAF | (nd.count << 24) | nd.start;
+}
+
+/* one inner record per split node, at the node's rank: the order in which the upload numbers the inner nodes of the
+ * file (depth first, child A before child B) */
+__global__ __launch_bounds__(256) void records_kernel(const GNode *nodes, uint32_t total, const uint32_t *rank, PTInnerRecord *inner,
+                                                      uint32_t *big, uint32_t *not_tame) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t c = nodes[i].child;
+    if (!c) return;
+    const GNode a = nodes[c], b = nodes[c + 1];
+    const uint32_t ra = a.child ? rank[c] : leaf_ref_of(a, big);
+    const uint32_t rb = b.child ? rank[c + 1] : leaf_ref_of(b, big);
+    PTInnerRecord r;
+    r.q[0] = make_float4(a.mn[0], a.mn[1], a.mx[0], a.mx[1]);
+    r.q[1] = make_float4(b.mn[0], b.mn[1], b.mx[0], b.mx[1]);
+    r.q[2] = make_float4(a.mn[2], a.mx[2], b.mn[2], b.mx[2]);
+    r.q[3] = make_float4(__uint_as_float(ra), __uint_as_float(rb), 0.0f, 0.0f);
+    inner[rank[i]] = r;
+    bool tame = true;
+    for (int k = 0; k < 3; k++)
+        tame = tame && pt_div_tame_coordinate(a.mn[k]) && pt_div_tame_coordinate(a.mx[k]) &&
+               pt_div_tame_coordinate(b.mn[k]) && pt_div_tame_coordinate(b.mx[k]);
+    if (!tame) atomicOr(not_tame, 1u);
+}
+
+/* The refit walks the tree bottom up and only needs children before parents: the split nodes' records level by
+ * level, deepest level first.  A split node's place among the split nodes of its level is half the distance of its
+ * child pair from the start of the next level (pairs are appended in the order of their parents). */
+__global__ __launch_bounds__(256) void refit_order_kernel(const GNode *nodes, uint32_t begin, uint32_t count, uint32_t next_begin,
+                                                          const uint32_t *rank, uint32_t out_base, uint32_t *order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t c = nodes[begin + i].child;
+    if (c) order[out_base + (c - next_begin) / 2u] = rank[begin + i];
+}
+
+/* triangle records in the tree's triangle order: the f32 operations of the upload (shader.wgsl:262-264) */
+__global__ __launch_bounds__(256) void tri_records_kernel(const float *tri9, const uint32_t *order, uint32_t n, PTTriRecord *out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    const float *t = tri9 + 9 * (size_t)order[p];
+    const float abx = t[3] - t[0], aby = t[4] - t[1], abz = t[5] - t[2];
+    const float acx = t[6] - t[0], acy = t[7] - t[1], acz = t[8] - t[2];
+    const float nx = aby * acz - abz * acy;
+    const float ny = abz * acx - abx * acz;
+    const float nz = abx * acy - aby * acx;
+    out[p].q[0] = make_float4(t[0], t[1], t[2], abx);
+    out[p].q[1] = make_float4(aby, abz, acx, acy);
+    out[p].q[2] = make_float4(acz, nx, ny, nz);
+}
+
+}  // namespace
+
+void pt_scratch_give_back(int device, void *p, size_t bytes) {
+    if (p) scratch_free(device, p, bytes);
+}
+
+void pt_resident_tree_free(PTResidentTree &t) {
+    if (t.d_inner) (void)hipFree(t.d_inner);
+    if (t.d_tris) (void)hipFree(t.d_tris);
+    if (t.d_big) (void)hipFree(t.d_big);
+    if (t.d_refit_order) (void)hipFree(t.d_refit_order);
+    t.d_inner = nullptr; t.d_tris = nullptr; t.d_big = nullptr; t.d_refit_order = nullptr;
+}
+
+int pt_gpu_build_resident(int device_ordinal, const float *triangles, uint32_t n, int max_depth, PTResidentTree &out, std::string &err) {
+    g_error.clear();
+    auto done = [&](int rc) { if (rc) { err = g_error; pt_resident_tree_free(out); } return rc; };
+    if (!triangles || n == 0 || max_depth < 0 || max_depth > 1024) return done(fail(PT_EINVAL, "bad argument"));
+    int rc = check_triangles(triangles, n);
+    if (rc) return done(rc);
+    if ((rc = select_device(device_ordinal))) return done(rc);
+    DeviceBuffers db;
+    db.device = device_ordinal;
+    Tree t;
+    hipStream_t stream = nullptr;
+    EventPairGuard ev;
+    hipError_t e = ev.create();
+    if (e != hipSuccess) return done(fail(PT_EHIP, std::string("hipEventCreate: ") + hipGetErrorString(e)));
+    if ((rc = grow_tree(triangles, n, max_depth, stream, ev.a, db, t))) return done(rc);
+
+    auto hip = [&](hipError_t he, const char *what) { return he == hipSuccess ? PT_OK : fail(PT_EHIP, std::string(what) + ": " + hipGetErrorString(he)); };
+    uint32_t *d_flag = nullptr;            /* "a bound outside the reciprocal slab test's range" */
+    if ((rc = hip(db.alloc(d_flag, 1), "hipMalloc"))) return done(rc);
+    const uint32_t depth = (uint32_t)t.level_begin.size() - 1u;        /* levels below the root */
+    const uint32_t inner_count = (t.total_nodes - 1u) / 2u;             /* every split node added one pair */
+
+    out.inner_count = inner_count; out.node_count = t.total_nodes; out.leaf_count = t.total_nodes - inner_count; out.depth = depth;
+    void *v = nullptr;
+    if ((rc = hip(scratch_alloc(device_ordinal, (inner_count ? inner_count : 1) * sizeof(PTInnerRecord), &v, &out.bytes_inner), "hipMalloc(inner records)"))) return done(rc);
+    out.d_inner = (PTInnerRecord *)v;
+    if ((rc = hip(scratch_alloc(device_ordinal, (size_t)n * sizeof(PTTriRecord), &v, &out.bytes_tris), "hipMalloc(triangle records)"))) return done(rc);
+    out.d_tris = (PTTriRecord *)v;
+    if ((rc = hip(scratch_alloc(device_ordinal, (size_t)n * sizeof(uint32_t), &v, &out.bytes_big), "hipMalloc(leaf counts)"))) return done(rc);
+    out.d_big = (uint32_t *)v;
+    if ((rc = hip(scratch_alloc(device_ordinal, (inner_count ? inner_count : 1) * sizeof(uint32_t), &v, &out.bytes_refit_order), "hipMalloc(refit order)"))) return done(rc);
+    out.d_refit_order = (uint32_t *)v;
+    if ((rc = hip(hipMemsetAsync(out.d_big, 0, (size_t)n * sizeof(uint32_t), stream), "hipMemset"))) return done(rc);
+    if ((rc = hip(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), stream), "hipMemset"))) return done(rc);
+    hipLaunchKernelGGL(records_kernel, grid_for(t.total_nodes, 256), dim3(256), 0, stream, t.d_nodes, t.total_nodes, t.d_rank, out.d_inner, out.d_big, d_flag);
+    hipLaunchKernelGGL(tri_records_kernel, grid_for(n, 256), dim3(256), 0, stream, t.d_tri9, t.d_order, n, out.d_tris);
+    /* stage h of a refit (1 = first) is level depth - h; the table has depth + 2 entries like the upload's table of heights */
+    out.refit_level_begin.assign((size_t)depth + 2, 0);
+    for (uint32_t h = 1; h <= depth; h++) {
+        const uint32_t level = depth - h, splits = t.level_count[level + 1] / 2u;
+        out.refit_level_begin[h + 1] = out.refit_level_begin[h] + splits;
+        hipLaunchKernelGGL(refit_order_kernel, grid_for(t.level_count[level], 256), dim3(256), 0, stream, t.d_nodes, t.level_begin[level],
+                           t.level_count[level], t.level_begin[level + 1], t.d_rank, out.refit_level_begin[h], out.d_refit_order);
+    }
+    uint32_t not_tame = 0;
+    GNode root;
+    if ((rc = hip(hipMemcpyAsync(&not_tame, d_flag, 4, hipMemcpyDeviceToHost, stream), "hipMemcpy"))) return done(rc);
+    if ((rc = hip(hipMemcpyAsync(&root, t.d_nodes, sizeof(GNode), hipMemcpyDeviceToHost, stream), "hipMemcpy"))) return done(rc);
+    if ((rc = hip(hipEventRecord(ev.b, stream), "hipEventRecord"))) return done(rc);
+    if ((rc = hip(hipGetLastError(), "kernel launch"))) return done(rc);
+    if ((rc = hip(hipStreamSynchronize(stream), "hipStreamSynchronize"))) return done(rc);
+    if ((rc = hip(hipEventElapsedTime(&out.build_ms, ev.a, ev.b), "hipEventElapsedTime"))) return done(rc);
+    out.tame = not_tame == 0;
+    if (inner_count) out.root_ref = 0;                      /* the root is split node number 0 */
+    else out.root_ref = root.count >= PT_REF_COUNT_ESCAPE ? (PT_REF_LEAF | (PT_REF_COUNT_ESCAPE << 24)) : (PT_REF_LEAF | (root.count << 24));
+    if (!inner_count && root.count >= PT_REF_COUNT_ESCAPE) {
+        if ((rc = hip(hipMemcpy(out.d_big, &root.count, 4, hipMemcpyHostToDevice), "hipMemcpy"))) return done(rc);
+    }
+    return PT_OK;
+}
+
+extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, uint32_t triangle_count, int max_depth,
+                                float *triangles_out, float **nodes_out, uint32_t *node_count, float *build_ms) {
+    g_error.clear();
+    if (!nodes_out || !node_count || max_depth < 0 || max_depth > 1024) return fail(PT_EINVAL, "bad argument");
+    if (triangle_count && (!triangles_in || !triangles_out)) return fail(PT_EINVAL, "bad argument");
+    const uint32_t n = triangle_count;
+    int rc = check_triangles(triangles_in, n);
+    if (rc) return rc;
+    if (build_ms) *build_ms = 0.0f;
+    if (n == 0) {
+        /* the reference writes the empty root: bounds (+inf, -inf), no triangles (main.rs:16-20) */
+        float *out = (float *)malloc(9 * sizeof(float));
+        if (!out) return fail(PT_ENOMEM, "out of memory");
+        const float inf = std::numeric_limits<float>::infinity();
+        out[0] = out[1] = out[2] = inf; out[3] = out[4] = out[5] = -inf; out[6] = out[7] = out[8] = 0.0f;
+        *nodes_out = out; *node_count = 1;
+        return PT_OK;
+    }
+    if ((rc = select_device(device_ordinal))) return rc;
+    DeviceBuffers db;
+    db.device = device_ordinal;
+    Tree t;
+    hipStream_t stream = nullptr;          /* the default stream: the call is synchronous */
+    EventPairGuard ev;
+    GB_TRY(ev.create());
+    if ((rc = grow_tree(triangles_in, n, max_depth, stream, ev.a, db, t))) return rc;
+    const uint32_t total_nodes = t.total_nodes;
+    float *d_nodes_out = nullptr, *d_tris_out = nullptr;
+    GB_TRY(db.alloc(d_nodes_out, 9 * (size_t)total_nodes));
+    GB_TRY(db.alloc(d_tris_out, 9 * (size_t)n));
+    hipLaunchKernelGGL(write_nodes_kernel, grid_for(total_nodes, 256), dim3(256), 0, stream, t.d_nodes, total_nodes, t.d_file_index, d_nodes_out);
+    hipLaunchKernelGGL(write_tris_kernel, grid_for(9 * (size_t)n, 256), dim3(256), 0, stream, t.d_tri9, t.d_order, n, d_tris_out);
+    GB_TRY(hipEventRecord(ev.b, stream));
     GB_TRY(hipGetLastError());
     GB_TRY(hipStreamSynchronize(stream));
-    if (build_ms) GB_TRY(hipEventElapsedTime(build_ms, ev0, ev1));
+    if (build_ms) GB_TRY(hipEventElapsedTime(build_ms, ev.a, ev.b));
 
     float *out = (float *)malloc(9 * (size_t)total_nodes * sizeof(float));
     if (!out) return fail(PT_ENOMEM, "out of memory");

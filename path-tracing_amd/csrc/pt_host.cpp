@@ -8,6 +8,7 @@
  */
 #include "../../include/pt_api.h"
 #include "pt_internal.h"
+#include "pt_scene_build.h"
 #include "pt_exact_div.h"
 
 #include <cmath>
@@ -97,6 +98,7 @@ struct pt_ctx {
     uint32_t *d_refit_flag = nullptr;
     bool refit_ok = false;
     std::string refit_why;
+    size_t bytes_inner = 0, bytes_tris = 0, bytes_big = 0, bytes_refit_order = 0;     /* sizes of the scene allocations */
 
     bool scene_loaded = false;
     uint32_t sphere_count = 0, tri_count = 0, node_count = 0;
@@ -783,6 +785,8 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     c->stack_entries = need;
     c->fast_div = rp.tame_bounds && getenv("PT_NO_FAST_DIV") == nullptr;
     c->refit_ok = rp.refit_ok; c->refit_why = rp.refit_why;
+    c->bytes_inner = n_inner * sizeof(PTInnerRecord); c->bytes_tris = trec.size() * sizeof(PTTriRecord);
+    c->bytes_big = rp.big.size() * sizeof(uint32_t); c->bytes_refit_order = 0;
     if (c->refit_ok && !rp.inner.empty()) {
         /* counting sort of the records by height: a refit walks the heights upwards */
         uint32_t top = 0;
@@ -794,9 +798,59 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
         for (uint32_t r = 0; r < rp.inner.size(); r++) order[fill[rp.height[r]]++] = r;
         HIP_TRY(c, hipMalloc(&c->d_refit_order, order.size() * sizeof(uint32_t)));
         HIP_TRY(c, hipMemcpy(c->d_refit_order, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->bytes_refit_order = order.size() * sizeof(uint32_t);
         c->refit_level_begin = begin;
     }
     c->scene_loaded = true;
+    return PT_OK;
+}
+
+int pt_rebuild_scene(pt_ctx *c, const float *triangles, uint32_t triangle_count, int max_depth, float *build_ms) {
+    if (!c) return PT_EINVAL;
+    if (build_ms) *build_ms = 0.0f;
+    if (!triangles || triangle_count == 0) return fail(c, PT_EINVAL, "pt_rebuild_scene needs at least one triangle");
+    if (c->params.flags & PT_FLAG_WIDE_BVH) return fail(c, PT_ESTATE, "pt_rebuild_scene does not build the four-wide tree (PT_FLAG_WIDE_BVH)");
+    PTResidentTree t;
+    std::string why;
+    int rc = pt_gpu_build_resident(c->device, triangles, triangle_count, max_depth, t, why);
+    if (rc) return fail(c, rc, "pt_rebuild_scene: " + why);
+    const int need = t.depth > 0 ? (int)t.depth : 1;
+    if (c->params.bvh_max_depth != 0 && t.depth > c->params.bvh_max_depth) {
+        pt_resident_tree_free(t);
+        return fail(c, PT_EINVAL, "the tree is " + std::to_string(t.depth) + " levels deep, pt_params.bvh_max_depth is " + std::to_string(c->params.bvh_max_depth));
+    }
+    if (need > pt_max_stack_entries()) {
+        pt_resident_tree_free(t);
+        return fail(c, PT_EINVAL, "BVH depth " + std::to_string(t.depth) + " exceeds the supported traversal stack");
+    }
+    hipError_t e = hipStreamSynchronize(c->stream);
+    uint32_t *spill = nullptr;
+    float *sph = c->d_spheres;
+    if (e == hipSuccess) {
+        size_t words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);
+        e = hipMalloc(&spill, (words ? words : 1) * sizeof(uint32_t));
+    }
+    if (e == hipSuccess && !sph) e = hipMalloc(&sph, 12 * sizeof(float));      /* no scene before: no spheres */
+    if (e != hipSuccess) {
+        pt_resident_tree_free(t);
+        if (spill) (void)hipFree(spill);
+        return fail_hip(c, e, "pt_rebuild_scene");
+    }
+    /* the old scene's arrays go to the builder's cache: the next rebuild of a scene of this size allocates nothing */
+    pt_scratch_give_back(c->device, c->d_inner, c->bytes_inner); pt_scratch_give_back(c->device, c->d_tris, c->bytes_tris);
+    pt_scratch_give_back(c->device, c->d_big, c->bytes_big); pt_scratch_give_back(c->device, c->d_refit_order, c->bytes_refit_order);
+    c->d_inner = nullptr; c->d_tris = nullptr; c->d_big = nullptr; c->d_refit_order = nullptr;
+    dev_free(c->d_spill); dev_free(c->d_tri9);
+    c->bytes_inner = t.bytes_inner; c->bytes_tris = t.bytes_tris; c->bytes_big = t.bytes_big; c->bytes_refit_order = t.bytes_refit_order;
+    c->d_inner = t.d_inner; c->d_tris = t.d_tris; c->d_big = t.d_big; c->d_refit_order = t.d_refit_order; c->d_spill = spill; c->d_spheres = sph;
+    c->refit_level_begin = t.refit_level_begin;
+    c->refit_ok = true; c->refit_why.clear();
+    c->tri_count = triangle_count; c->node_count = t.node_count;
+    c->root_ref = t.root_ref; c->depth = t.depth; c->inner_count = t.inner_count; c->leaf_count = t.leaf_count;
+    c->stack_entries = need;
+    c->fast_div = t.tame && getenv("PT_NO_FAST_DIV") == nullptr;
+    c->scene_loaded = true;
+    if (build_ms) *build_ms = t.build_ms;
     return PT_OK;
 }
 

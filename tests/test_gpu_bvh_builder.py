@@ -136,3 +136,21 @@ def test_pt_prepare_with_the_gpu_builder_reproduces_the_reference_teapot_pair(tm
     assert "built on GPU 0" in res.stdout
     assert open(tmp_path / "t.bin", "rb").read() == open(os.path.join(obj, "teapot.bin"), "rb").read()
     assert open(tmp_path / "t_bvh.bin", "rb").read() == open(os.path.join(obj, "teapot_bvh.bin"), "rb").read()
+
+
+def test_scratch_cache_is_reused_and_can_be_released(pkg, scenes):
+    """The builder keeps its scratch blocks for the next build; pt_bvh_build_gpu_release_cache hands them back."""
+    import torch
+    L = pkg.load_library()
+    tris = scenes.load_bin("dragon_80k.bin")
+    L.pt_bvh_build_gpu_release_cache()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    a = pkg.bvh_build_gpu(tris, 32)
+    held = free0 - torch.cuda.mem_get_info(0)[0]
+    assert held > 10 * tris.nbytes                      # centres, bounds, orders, nodes, buckets stay allocated
+    b = pkg.bvh_build_gpu(tris, 32)                     # second build out of the cache: nothing new is allocated
+    assert free0 - torch.cuda.mem_get_info(0)[0] <= held + (8 << 20)
+    assert np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[0]), bits(b[0]))
+    L.pt_bvh_build_gpu_release_cache()
+    assert free0 - torch.cuda.mem_get_info(0)[0] < (64 << 20)

@@ -136,3 +136,77 @@ def test_refit_refusals(pkg, scenes):
         r.upload_scene([], t2, b2)
         with pytest.raises(pkg.PtError, match="four-wide"):
             r.refit_scene(t2)
+
+
+def _state(pkg, r, frames=2):
+    ids, dist = r.primary_hits()
+    r.reset_counters()
+    r.render_frames(0, frames)
+    return ids, dist, r.read_accum(4).copy(), r.counters(), r.scene_info()
+
+
+@pytest.mark.parametrize("mesh,depth", [("dragon_8k", 24), ("teapot", 16), ("teapot", 3), ("small_knight", 0), ("dragon_80k", 32)])
+def test_rebuild_on_the_gpu_equals_build_files_and_upload(pkg, scenes, mesh, depth):
+    """pt_rebuild_scene(triangles) == pt_upload_scene(pt_bvh_build(triangles)): images, ids, distances, work counters and
+    tree statistics, from shuffled triangles; depth 3 gives leaves of more than 127 triangles, depth 0 a single leaf."""
+    tris = scenes.load_bin(mesh + ".bin")
+    tris = tris[np.random.default_rng(3).permutation(len(tris))]
+    cfg = scenes.config({"dragon_8k": 2, "teapot": 1, "small_knight": 1, "dragon_80k": 3}[mesh])
+    spheres = scenes.spheres_for(cfg["spheres"])
+    p = pkg.default_params(width=128, height=72, rays_per_pixel=2, max_bounce_count=4,
+                           flags=pkg.PT_FLAG_EXACT_MATH | pkg.PT_FLAG_COUNT_WORK)
+    bt, bn = pkg.bvh_build(tris, depth)
+    with pkg.Renderer(p) as a, pkg.Renderer(p) as b:
+        a.upload_scene(spheres, *scenes.mesh("knight"))        # some other scene first: its spheres stay
+        a.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        ms = a.rebuild_scene(tris, depth)
+        assert ms > 0
+        b.upload_scene(spheres, bt, bn)
+        b.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        sa, sb = _state(pkg, a), _state(pkg, b)
+        assert np.array_equal(sa[0], sb[0])
+        assert np.array_equal(bits(sa[1]), bits(sb[1]))
+        assert np.array_equal(bits(sa[2]), bits(sb[2]))
+        assert sa[3] == sb[3]
+        assert sa[4] == sb[4]
+        if mesh != "small_knight":
+            assert (sa[0] >= 0).sum() > 100
+        # the rebuilt scene can be refitted like an uploaded one
+        moved = deform(bt, 1.0)
+        a.refit_scene(moved)
+        b.upload_scene(spheres, moved, refit_nodes(moved, bn))
+        sa, sb = _state(pkg, a), _state(pkg, b)
+        assert np.array_equal(sa[0], sb[0])
+        assert np.array_equal(bits(sa[1]), bits(sb[1]))
+        assert np.array_equal(bits(sa[2]), bits(sb[2]))
+        assert sa[3] == sb[3]
+
+
+def test_rebuild_into_an_empty_context_and_refusals(pkg, scenes):
+    tris = scenes.load_bin("teapot.bin")
+    p = pkg.default_params(width=64, height=36, rays_per_pixel=1, flags=pkg.PT_FLAG_EXACT_MATH)
+    cfg = scenes.config(1)
+    with pkg.Renderer(p) as a, pkg.Renderer(p) as b:
+        a.rebuild_scene(tris, 16)                                 # no scene before: no spheres
+        a.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        b.upload_scene([], *pkg.bvh_build(tris, 16))
+        b.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        ia, da = a.primary_hits()
+        ib, db = b.primary_hits()
+        assert np.array_equal(ia, ib) and np.array_equal(bits(da), bits(db))
+        with pytest.raises(pkg.PtError, match="at least one triangle"):
+            a.rebuild_scene(np.zeros((0, 9), F), 16)
+        bad = tris.copy()
+        bad[0, 0] = np.nan
+        with pytest.raises(pkg.PtError, match="not finite"):
+            a.rebuild_scene(bad, 16)
+        ia2, _ = a.primary_hits()                                 # a refused rebuild leaves the scene as it was
+        assert np.array_equal(ia, ia2)
+    pd = pkg.default_params(width=64, height=36, rays_per_pixel=1, bvh_max_depth=4)
+    with pkg.Renderer(pd) as r:
+        with pytest.raises(pkg.PtError, match="levels deep"):
+            r.rebuild_scene(tris, 16)
+    pw = pkg.default_params(width=64, height=36, rays_per_pixel=1, flags=pkg.PT_FLAG_WIDE_BVH)
+    with pkg.Renderer(pw) as r:
+        with pytest.raises(pkg.PtError, match="four-wide"):
+            r.rebuild_scene(tris, 16)

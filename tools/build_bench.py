@@ -43,4 +43,10 @@ with pkg.Renderer(p) as r:
         t0 = time.perf_counter()
         r.refit_scene(moved)
         ts.append((time.perf_counter() - t0) * 1e3)
+    tr = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ms = r.rebuild_scene(tris, depth)
+        tr.append(((time.perf_counter() - t0) * 1e3, ms))
 print("pt_refit_scene: %.2f ms per call (best of %d); pt_upload_scene of the same scene (host repack + copies): %.0f ms" % (min(ts), reps, up_ms))
+print("pt_rebuild_scene (tree + records on the GPU, nothing copied back): %.2f ms per call, %.2f ms of it on the device after the upload" % min(tr))

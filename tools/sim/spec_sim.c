@@ -201,3 +201,40 @@ int sim_run(const sim_policy *pol, sim_result *out) {
     free(L); free(wave_time); free(wave_done);
     return 0;
 }
+
+/* How far do all rays that leave one surface point walk the tree together?  For the primary hit point o of every pixel
+ * of a region: the number of levels, from the root, at which o lies strictly inside one child box and strictly outside
+ * the other on some axis (then every ray with finite, non-zero direction takes the first child as the near one and only
+ * the other box needs a test of its own).  hist[k] = pixels whose walk in common is k levels long (k < 64);
+ * out[0] = hit pixels, out[1] = sum of k, out[2] = sum of the depth at which the containing chain ends in a leaf or fails. */
+void sim_prefix(const orc_params *p, const orc_scene *s, const float cam[3], const float rot[3],
+                uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint64_t hist[64], uint64_t out[4]) {
+    memset(hist, 0, 64 * sizeof(uint64_t)); memset(out, 0, 4 * sizeof(uint64_t));
+    for (uint32_t y = y0; y < y0 + h; y++) for (uint32_t x = x0; x < x0 + w; x++) {
+        float o[3], d[3]; uint32_t pixel_index;
+        orc_primary_ray(p, cam, rot, x, y, o, d, &pixel_index);
+        orc_hit first;
+        orc_calculate_ray_collision(p, s, o, d, &first, NULL);
+        if (!first.did_hit) continue;
+        const float q[3] = {first.position.x, first.position.y, first.position.z};
+        uint32_t node = 0, k = 0;
+        int ended_in_leaf = 0;
+        for (;;) {
+            const float *nd = s->bvh + 9 * (size_t)node;
+            if (nd[8] == 0.0f) { ended_in_leaf = 1; break; }
+            const uint32_t ca = (uint32_t)nd[8], cb = ca + 1;
+            const float *a = s->bvh + 9 * (size_t)ca, *b = s->bvh + 9 * (size_t)cb;
+            int in_a = 1, in_b = 1, out_a = 0, out_b = 0;
+            for (int ax = 0; ax < 3; ax++) {
+                if (!(a[ax] < q[ax] && q[ax] < a[3 + ax])) in_a = 0;
+                if (!(b[ax] < q[ax] && q[ax] < b[3 + ax])) in_b = 0;
+                if (q[ax] < a[ax] || q[ax] > a[3 + ax]) out_a = 1;
+                if (q[ax] < b[ax] || q[ax] > b[3 + ax]) out_b = 1;
+            }
+            if (in_a && out_b) node = ca; else if (in_b && out_a) node = cb; else break;
+            k++;
+        }
+        out[0]++; out[1] += k; out[2] += ended_in_leaf;
+        hist[k < 63 ? k : 63]++;
+    }
+}

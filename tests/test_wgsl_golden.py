@@ -187,3 +187,52 @@ def test_gpu_functions_equal_the_shader(G, pkg, scenes):
         x = r.probe_intersections(rays, G["box_bounds"], G["tri_vertices"], G["sph_records"][:, :4])
         hit = G["sph_hits"][:, 0] == 1.0
         assert np.array_equal(x["sphere_hit"], hit) and same(x["sphere_distance"][hit], G["sph_hits"][hit, 1])
+
+
+# ---- the other benchmark scenes: tests/golden/wgsl_golden_scenes.npz (make_wgsl_golden_scenes.py) ----
+SCENES_GOLDEN = os.path.join(ROOT, "tests", "golden", "wgsl_golden_scenes.npz")
+
+
+@pytest.fixture(scope="module")
+def GS():
+    return dict(np.load(SCENES_GOLDEN))
+
+
+def _scene_case(GS, n, scenes):
+    cfg = scenes.config(n)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    spheres = scenes.spheres_for(cfg["spheres"])
+    w, h, rpp, bounces = [int(x) for x in GS["cfg%d_size_rpp_bounces" % n]]
+    assert bounces == cfg["max_bounce_count"]
+    return cfg, tris, bvh, spheres, w, h, rpp, bounces
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5])
+def test_whole_frames_of_the_other_scenes(GS, oracle_shared, scenes, n):
+    """fs_main of the reference shader over every pixel for frame_count 0, 1 and 13 (wrapped seed term) on the legacy
+    dragon_8k file (21 levels, a corrupt link), the 87 k-triangle dragon, the 784 k-triangle benchmark mesh and the knight with 16
+    spheres and 12 bounces"""
+    o = oracle_shared
+    cfg, tris, bvh, spheres, w, h, rpp, bounces = _scene_case(GS, n, scenes)
+    p = o.default_params(width=w, height=h, rays_per_pixel=rpp, max_bounce_count=bounces)
+    sc = o.scene(spheres, tris, bvh)
+    acc = np.zeros((h, w, 4), dtype=np.float32)
+    want = GS["cfg%d_frames_accum" % n]
+    for k, fc in enumerate(GS["frame_counts"]):
+        o.render_frames(p, sc, cfg["camera_position"], cfg["camera_rotation"], int(fc), 1, accum=acc)
+        assert same(acc[..., :3], want[k]), "configuration %d, frame_count %d" % (n, fc)
+    assert (want[-1] > 0).any() and len(np.unique(want[-1])) > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 3, 4, 5])
+def test_gpu_frames_of_the_other_scenes_equal_the_shader(GS, pkg, scenes, n):
+    cfg, tris, bvh, spheres, w, h, rpp, bounces = _scene_case(GS, n, scenes)
+    p = pkg.default_params(width=w, height=h, rays_per_pixel=rpp, max_bounce_count=bounces, flags=pkg.PT_FLAG_EXACT_MATH)
+    want = GS["cfg%d_frames_accum" % n]
+    with pkg.Renderer(p) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        for k, fc in enumerate(GS["frame_counts"]):
+            r.render_frames(int(fc), 1)
+            assert same(r.read_accum(4)[..., :3], want[k]), "configuration %d, frame_count %d" % (n, fc)

@@ -1,17 +1,19 @@
 #!/usr/bin/env python3
 """Headline benchmark: Msamples/s of the path-tracing hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--shard pixels|frames]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--shard frames|pixels|both]
 
 A "step" is one complete render of the configuration (default: benchmark configuration 4,
 dragon_800k SYNTHETIC STAND-IN, 1920x1080, 256 spp = 16 frames x 16 rays/pixel,
-max_bounce_count 8), scene already resident in HBM.  For N > 1 the driver starts
-one process per GPU with torch.distributed.run; the render is sharded over ranks either in
-8x8-pixel tiles (default: every rank renders all frames of its tiles, running mean as on one
-GPU, result equal to the single-GPU image bit for bit) or by frames (--shard frames: rank r
-renders frames r, r+N, ... into a sum; the split the reference's accumulation unit suggests),
-and the buffers are combined with ONE RCCL sum reduce to rank 0 per step (strong scaling:
-total samples fixed).  Rank 0 prints ONE JSON line.
+max_bounce_count 8), scene already resident in HBM.  For N > 1 there is one process per GPU
+(started by torch.distributed.run; a plain `python bench.py --gpus N` starts that launcher itself,
+as a child process, before anything in this process has touched the GPU).  The render is sharded
+over ranks by frames (the samples of a pixel are split: rank r renders frames r, r+N, ... into a
+sum; the reference's own accumulation unit) or in 8x8-pixel tiles (every rank renders all frames
+of its tiles, running mean as on one GPU, result equal to the single-GPU image bit for bit), and
+the buffers are combined with ONE RCCL sum reduce to rank 0 per step (strong scaling: total
+samples fixed).  The default for N > 1 times both splits; `value` is the frame split's, the
+other one is listed under `splits`.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
   roofline     - the path (bounce) kernel, 98 % of the time.  It streams nothing: its working set
@@ -62,14 +64,49 @@ def metric_name(cfg):
     return "Msamples/s at %s %s, %d bounces" % (res, mesh, cfg["max_bounce_count"])
 
 
+def host_cores():
+    """Threads for the CPU baseline: every core this process may run on - the affinity mask, cut down to the
+    cgroup's CPU quota where one is set.  Returns (count, how it was found)."""
+    try:
+        mask = len(os.sched_getaffinity(0))
+    except AttributeError:
+        mask = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()
+            if q != "max":
+                quota = max(1, int(float(q) / float(period) + 0.999))
+    except (OSError, ValueError):
+        pass
+    n = max(1, min(mask, quota) if quota else mask)
+    return n, "affinity mask %d cores, cgroup quota %s, OMP_NUM_THREADS %s" % (
+        mask, quota if quota else "none", os.environ.get("OMP_NUM_THREADS", "unset"))
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start torch.distributed.run as a CHILD process (this process
+    has not imported torch or touched the GPU), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=4)
-    ap.add_argument("--shard", choices=("pixels", "frames"), default="pixels",
-                    help="N > 1: 8x8-pixel tiles (bit-identical image) or the frames of the render (sum + scale)")
+    ap.add_argument("--shard", choices=("frames", "pixels", "both"), default="both",
+                    help="N > 1: the frames of the render (samples per pixel split, sum + scale), 8x8-pixel tiles "
+                         "(bit-identical image), or both one after the other (value = the frame split)")
     ap.add_argument("--wide", action="store_true",
                     help="PT_FLAG_WIDE_BVH: four-wide tree (not the reference's visit order; reported under its own workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,6 +114,8 @@ def main():
     args = ap.parse_args()
     if args.wide:
         args.no_count = True          # the work counters follow the reference's binary walk
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import numpy as np
     import torch
@@ -85,9 +124,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be started with torch.distributed.run (one process per GPU)")
+    if args.gpus != world and args.gpus > 1:
+        sys.exit("bench.py --gpus %d runs under a launcher that started %d ranks" % (args.gpus, world))
     # PT_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo, to rehearse the N > 1 code path
     # on a one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing
     rehearsal = os.environ.get("PT_BENCH_REHEARSAL") == "1"
@@ -126,19 +164,6 @@ def main():
 
     r = make_renderer(pkg.PT_FLAG_WIDE_BVH if args.wide else 0)
     info = r.scene_info()
-    # the image ends on rank 0
-    sharded = ShardedRenderer(r, rank, world, mode=args.shard, collective="reduce") if grouped else None
-    phase = {"render_s": 0.0, "collective_s": 0.0}
-
-    def step(timed=False):
-        if sharded is not None:
-            sharded.render(0, n_frames)
-            if timed:
-                for k in phase:
-                    phase[k] += sharded.last_timing[k]
-        else:
-            r.render_frames(0, n_frames)          # the reference protocol: running mean over frames
-            r.synchronize()
 
     def fence():
         torch.cuda.synchronize()
@@ -146,39 +171,64 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    r.reset_timing()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(timed=True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timing = r.timing()
-    per_rank = None
-    if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        mine = {"rank": rank, "path_ms_per_step": timing["path_ms"] / args.steps,
-                "primary_ms_per_step": timing["primary_ms"] / args.steps,
-                "resolve_ms_per_step": timing["resolve_ms"] / args.steps,
-                "render_ms_per_step": phase["render_s"] / args.steps * 1e3,
-                "collective_ms_per_step": phase["collective_s"] / args.steps * 1e3,
-                "frames_per_step": timing["frames"] / args.steps}
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
+    def run_split(mode):
+        """W warm-up steps, then K timed steps of one way to split the render; returns the time (maximum over ranks),
+        the library's event timing of this rank and, for N > 1, every rank's figures."""
+        # the image ends on rank 0
+        sharded = ShardedRenderer(r, rank, world, mode=mode, collective="reduce",
+                                  force_collective=world == 1) if grouped else None
+        phase = {"render_s": 0.0, "collective_s": 0.0}
+
+        def step(timed=False):
+            if sharded is not None:
+                sharded.render(0, n_frames)
+                if timed:
+                    for k in phase:
+                        phase[k] += sharded.last_timing[k]
+            else:
+                r.render_frames(0, n_frames)          # the reference protocol: running mean over frames
+                r.synchronize()
+
+        for _ in range(args.warmup):
+            step()
+        r.reset_timing()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timed=True)
+        fence()
+        elapsed = time.perf_counter() - t0
+        timing = r.timing()
+        per_rank = None
+        if grouped:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            mine = {"rank": rank, "path_ms_per_step": timing["path_ms"] / args.steps,
+                    "primary_ms_per_step": timing["primary_ms"] / args.steps,
+                    "resolve_ms_per_step": timing["resolve_ms"] / args.steps,
+                    "render_ms_per_step": phase["render_s"] / args.steps * 1e3,
+                    "collective_ms_per_step": phase["collective_s"] / args.steps * 1e3,
+                    "frames_per_step": timing["frames"] / args.steps}
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
+        return elapsed, timing, per_rank
+
+    # the split `value` is quoted on comes first: frames (samples per pixel split over the GPUs) unless --shard pixels
+    modes = ["single"] if not grouped else (["frames", "pixels"] if args.shard == "both" else [args.shard])
+    runs = {m: run_split(m) for m in modes}
+    shard_mode = modes[0]
+    elapsed, timing, per_rank = runs[shard_mode]
+    parallelism_of = {
+        "single": "single GPU, running mean",
+        "pixels": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world,
+        "frames": "samples per pixel split over %d GPUs by frame (frames f = rank mod %d summed per GPU), one RCCL sum "
+                  "reduce to rank 0 per step, scaled by 1/frames" % (world, world),
+    }
 
     result = None
     if rank == 0:
         value = samples_per_step * args.steps / elapsed / 1e6
-        if world == 1:
-            parallelism = "single GPU, running mean"
-        elif args.shard == "pixels":
-            parallelism = "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world
-        else:
-            parallelism = "frames f = rank (mod %d) summed per GPU, one RCCL sum reduce to rank 0 per step, scaled by 1/frames" % world
         result = {
             "metric": metric_name(cfg),
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
@@ -193,7 +243,7 @@ def main():
                 "resolution": [W, H], "spp": spp, "frames": n_frames, "rays_per_pixel": rpp,
                 "max_bounce_count": cfg["max_bounce_count"], "triangles": int(len(tris)),
                 "bvh_nodes": int(len(bvh)), "bvh_depth": info["bvh_depth"], "spheres": int(len(spheres)),
-                "parallelism": parallelism,
+                "parallelism": parallelism_of[shard_mode],
             },
             "kernel_ms_per_frame": {k: timing[k] / max(1, timing["frames"])
                                     for k in ("primary_ms", "path_ms", "resolve_ms")},
@@ -202,6 +252,10 @@ def main():
         if grouped:
             result["per_rank"] = per_rank
             result["collective_ms_per_step"] = max(p["collective_ms_per_step"] for p in per_rank)
+            result["splits"] = {m: {"value": samples_per_step * args.steps / e / 1e6, "ms_per_step": e / args.steps * 1e3,
+                                    "parallelism": parallelism_of[m], "per_rank": pr,
+                                    "collective_ms_per_step": max(p["collective_ms_per_step"] for p in pr)}
+                                for m, (e, _, pr) in runs.items()}
             result["predicted_efficiency"] = dict(PREDICTED_EFFICIENCY, note="pixel sharding, kernel time only, from "
                                                   "single-GPU runs of one rank's share (tools/shard_cost.py); no N > 1 "
                                                   "run on hardware has been compared with it yet")
@@ -255,7 +309,7 @@ def main():
             roof["note"] = "the counter pass describes the single-GPU launch shape; see per_rank for this run"
         if not args.no_count and timing["frames"]:
             rc = make_renderer(pkg.PT_FLAG_COUNT_WORK)
-            if world > 1 and args.shard == "pixels":
+            if world > 1 and shard_mode == "pixels":
                 rc.set_pixel_shard(rank, world)          # the launches this rank timed
                 rc.render_frames(0, n_frames)
                 frames_local = n_frames
@@ -271,7 +325,7 @@ def main():
             path_bytes = 36 * cnt["path_kernel_box_tests"] + 36 * cnt["path_kernel_tri_tests"] \
                 + 48 * S * cnt["path_kernel_ray_casts"]
             per_launch = path_bytes / launches_per_step
-            pixels_local = W * H // world if (world > 1 and args.shard == "pixels") else W * H
+            pixels_local = W * H // world if (world > 1 and shard_mode == "pixels") else W * H
             # casts that ran: the path kernel's, plus one primary cast per pixel and batch of frames
             executed = cnt["path_kernel_ray_casts"] + pixels_local * launches_per_step
             roof.update({
@@ -297,15 +351,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         om = entry.load_oracle_module()
         oracle = om.Oracle(shared_math=False)
-        try:
-            avail = len(os.sched_getaffinity(0))
-        except AttributeError:
-            avail = os.cpu_count() or 1
-        # the box gives a one-GPU job 16 host cores and says so in OMP_NUM_THREADS
-        cores = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", "16"))))
+        cores, cores_note = host_cores()
         op = oracle.default_params(width=W, height=H, rays_per_pixel=rpp, max_bounce_count=cfg["max_bounce_count"])
         sc = oracle.scene(spheres, tris, bvh)
-        cpu_frames = min(n_frames, 8)      # ~10-20 s of CPU work on 16 cores
+        cpu_frames = min(n_frames, 8)      # 10-30 s of CPU work on 16 cores
         acc = np.zeros((H, W, 4), np.float32)
         t0 = time.perf_counter()
         oracle.render_frames(op, sc, cfg["camera_position"], cfg["camera_rotation"], 0, cpu_frames,
@@ -313,7 +362,7 @@ def main():
         cpu_s = time.perf_counter() - t0
         cpu_samples = W * H * rpp * cpu_frames
         result["cpu_baseline"] = {
-            "value": cpu_samples / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "value": cpu_samples / cpu_s / 1e6, "unit": "Msamples/s", "cores": cores, "cores_note": cores_note, "kind": "port",
             "sample": "frames 0..%d of %d of the same workload, all pixels (%.1f M of %.1f M samples), %.1f s; "
                       "C restatement of shader.wgsl with OpenMP over rows (the reference needs wgpu and cannot run here)"
                       % (cpu_frames - 1, n_frames, cpu_samples / 1e6, samples_per_step / 1e6, cpu_s),

@@ -179,9 +179,12 @@ int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames)
  * pt_render_frames.  Needs 256 + 36 * width * height + 16 * roundup64(width * height) *
  * rays_per_pixel bytes for a one-frame batch (more frames per batch are used when they fit);
  * PT_EINVAL with the two byte counts in the message when that exceeds the array.  The kernels are not
- * timed (pt_get_timing does not see them).  All contexts of one GPU share that GPU's array: calls
- * that overlap in time on one GPU (different contexts or threads) race; run them one after the
- * other (pt_synchronize between contexts). */
+ * timed (pt_get_timing does not see them).  The layout is sized for the worst case (every pixel a hit
+ * pixel), so a large image with few hits is refused although it would fit.  All contexts of one GPU
+ * share that GPU's array, so their static renders must not overlap in time: run them one after the
+ * other (pt_synchronize between contexts).  A call that finds another context's static render still
+ * running on its GPU returns PT_ESTATE and renders nothing (the check is an event query, created at
+ * pt_create); calls of one context are ordered by its stream. */
 int pt_render_frames_static(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames);
 size_t pt_static_scratch_bytes(void);
 

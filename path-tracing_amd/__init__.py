@@ -20,6 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpt_hip.so")
 
 PT_OK = 0
+PT_EINVAL, PT_EHIP, PT_ENOMEM, PT_EIO, PT_ESTATE = -1, -2, -3, -4, -5      # include/pt_api.h
 PT_FLAG_EXACT_MATH = 1
 PT_FLAG_COUNT_WORK = 2
 PT_FLAG_WIDE_BVH = 4

@@ -36,6 +36,12 @@ namespace {
 
 std::mutex g_static_scratch_mutex;
 unsigned char *g_static_scratch[PT_MAX_DEVICES];     /* device address of `scratch` on each GPU, or null */
+/* Guard against two static renders that overlap on one GPU (they would share the array): the context that last
+ * enqueued one (by serial number, 0 = none) and an event recorded behind its kernels.  The event is created here,
+ * at set-up, so that the render call itself creates nothing. */
+hipEvent_t g_static_done[PT_MAX_DEVICES];
+unsigned long long g_static_owner[PT_MAX_DEVICES];
+unsigned long long g_next_serial = 1;
 
 /* with `device` current */
 hipError_t static_scratch_lookup(int device) {
@@ -44,6 +50,8 @@ hipError_t static_scratch_lookup(int device) {
     if (g_static_scratch[device]) return hipSuccess;
     void *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    e = hipEventCreateWithFlags(&g_static_done[device], hipEventDisableTiming);
     if (e != hipSuccess) return e;
     g_static_scratch[device] = (unsigned char *)ptr;
     return hipSuccess;
@@ -56,6 +64,7 @@ struct EventPair { hipEvent_t start, stop; int kind; };
 }  // namespace
 
 struct pt_ctx {
+    unsigned long long serial = 0;     /* distinguishes contexts for the static-scratch guard (addresses are reused) */
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;
@@ -667,6 +676,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (!c) return fail(nullptr, PT_ENOMEM, "out of host memory");
     c->device = device_ordinal;
     c->params = *params;
+    { std::lock_guard<std::mutex> lock(g_static_scratch_mutex); c->serial = g_next_serial++; }
     if (const char *e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_min = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 6) c->leaf_shift = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }
@@ -912,7 +922,25 @@ int pt_render_frames_static(pt_ctx *c, uint32_t first_frame_count, uint32_t n_fr
     WorkBuffers wb;
     int rc = static_work_buffers(c, n_frames, wb);
     if (rc) return rc;
-    return render_impl(c, first_frame_count, n_frames, 1, 0, &wb);
+    /* All contexts of a GPU share the array.  Calls of ONE context are ordered by its stream; a call that finds
+     * another context's static render still running on this GPU is refused instead of racing with it. */
+    std::lock_guard<std::mutex> lock(g_static_scratch_mutex);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (g_static_owner[c->device] != 0 && g_static_owner[c->device] != c->serial) {
+        hipError_t q = hipEventQuery(g_static_done[c->device]);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            return fail(c, PT_ESTATE, "pt_render_frames_static: another context's static render is still running on this GPU "
+                                      "(they share one scratch array; synchronise that context first)");
+        }
+        if (q != hipSuccess) return fail_hip(c, q, "hipEventQuery(static scratch guard)");
+    }
+    rc = render_impl(c, first_frame_count, n_frames, 1, 0, &wb);
+    /* whatever was enqueued (even by a call that failed half way) uses the array until this point of the stream */
+    g_static_owner[c->device] = c->serial;
+    hipError_t e = hipEventRecord(g_static_done[c->device], c->stream);
+    if (rc == PT_OK && e != hipSuccess) return fail_hip(c, e, "hipEventRecord(static scratch guard)");
+    return rc;
 }
 
 size_t pt_static_scratch_bytes(void) { return (size_t)PT_STATIC_SCRATCH_BYTES; }

@@ -72,6 +72,29 @@ def render_pixel_sharded(render_owned, all_reduce, first_frame, n_frames):
     all_reduce()
 
 
+def combine(buffer, world_size, group=None, collective="all_reduce", force_collective=False):
+    """Sums `buffer` (a torch tensor, CPU or GPU) over the `world_size` ranks that share a render.
+
+    A renderer of ONE rank issues no collective, whatever process groups the job has: its image is complete, and a
+    collective on the job's default group would add unrelated images (or hang, if the other ranks are not rendering).
+    `force_collective` runs the collective on a one-rank group all the same (a rehearsal of the RCCL calls on one GPU).
+    The group the collective runs on must have exactly `world_size` ranks."""
+    import torch.distributed as dist
+
+    if world_size == 1 and not force_collective:
+        return False
+    if not dist.is_initialized():
+        raise RuntimeError("a render sharded over %d ranks needs an initialised torch.distributed process group" % world_size)
+    n = dist.get_world_size(group)
+    if n != world_size:
+        raise ValueError("the render is sharded over %d ranks but the process group has %d" % (world_size, n))
+    if collective == "reduce":
+        dist.reduce(buffer, dst=dist.get_global_rank(group, 0) if group is not None else 0, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=group)
+    return True
+
+
 class ShardedRenderer:
     """A Renderer whose accumulation buffer is a torch CUDA tensor so that
     torch.distributed (backend "nccl" = RCCL) can reduce it.
@@ -82,9 +105,10 @@ class ShardedRenderer:
     per call and is what the collective sums.  frames mode sums frame means and divides by their
     number, which is the running mean only when the render starts at frame 0."""
 
-    def __init__(self, renderer, rank, world_size, group=None, mode="pixels", collective="all_reduce"):
-        """collective: "all_reduce" leaves the image on every rank, "reduce" on rank 0 only (what a
-        host that displays or stores the image needs; half the traffic per link on a ring)."""
+    def __init__(self, renderer, rank, world_size, group=None, mode="pixels", collective="all_reduce", force_collective=False):
+        """collective: "all_reduce" leaves the image on every rank, "reduce" on rank 0 of the group only (what a
+        host that displays or stores the image needs; half the traffic per link on a ring).  `group` must have
+        exactly `world_size` ranks.  With world_size 1 no collective runs unless `force_collective` asks for it."""
         import torch
 
         if mode not in ("pixels", "frames"):
@@ -92,6 +116,7 @@ class ShardedRenderer:
         if collective not in ("all_reduce", "reduce"):
             raise ValueError("collective must be 'all_reduce' or 'reduce'")
         self.collective = collective
+        self.force_collective = bool(force_collective)
         self.r = renderer
         self.rank, self.world_size, self.group, self.mode = rank, world_size, group, mode
         renderer.set_pixel_shard(*((rank, world_size) if mode == "pixels" else (0, 1)))
@@ -107,7 +132,6 @@ class ShardedRenderer:
         import time
 
         import torch
-        import torch.distributed as dist
 
         if self.mode == "frames":
             if first_frame != 0:
@@ -120,12 +144,7 @@ class ShardedRenderer:
             t1 = time.perf_counter()
             if self.mode == "pixels":
                 self.buffer.copy_(self.owned)     # the collective must not touch the running means kept in `owned`
-            # a process group of one rank still runs its collective (a rehearsal of the RCCL calls on one GPU)
-            if self.world_size > 1 or dist.is_initialized():
-                if self.collective == "reduce":
-                    dist.reduce(self.buffer, dst=0, op=dist.ReduceOp.SUM, group=self.group)
-                else:
-                    dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM, group=self.group)
+            combine(self.buffer, self.world_size, self.group, self.collective, self.force_collective)
             torch.cuda.synchronize()
             self.last_timing = {"render_s": t1 - t0, "collective_s": time.perf_counter() - t1}
 

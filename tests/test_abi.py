@@ -100,3 +100,40 @@ def test_missing_library_fails_loudly(pkg, monkeypatch):
     monkeypatch.setattr(pkg, "LIB_PATH", "/nonexistent/libpt_hip.so")
     with pytest.raises(FileNotFoundError):
         pkg.load_library()
+
+
+def _rust_blocks():
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    return "\n".join(re.findall(r"```rust\n(.*?)```", text, flags=re.S))
+
+
+def test_integration_document_params_struct_matches_the_abi(pkg):
+    """The Rust FFI stub a maintainer would paste from INTEGRATION.md: its `pt_params` must have the header's fields,
+    in the header's order and with the header's types, or the library reads a struct of another size."""
+    rust = _rust_blocks()
+    m = re.search(r"#\[repr\(C\)\]\s*pub struct pt_params\s*\{(.*?)\}", rust, flags=re.S)
+    assert m, "INTEGRATION.md has no #[repr(C)] struct pt_params"
+    fields = re.findall(r"pub\s+([a-z_0-9]+)\s*:\s*(\[f32;\s*3\]|u32|f32)", m.group(1))
+    ctype = {"u32": C.c_uint32, "f32": C.c_float}
+    want = []
+    for name, t in pkg.PtParams._fields_:
+        want.append((name, "[f32;3]" if t is C.c_float * 3 else {C.c_uint32: "u32", C.c_float: "f32"}[t]))
+    got = [(n, t.replace(" ", "")) for n, t in fields]
+    assert got == want
+    size = sum(12 if t == "[f32;3]" else C.sizeof(ctype[t]) for _, t in got)
+    assert size == C.sizeof(pkg.PtParams)
+
+
+def test_integration_document_functions_match_the_header():
+    """Every function the Rust stub declares exists in include/pt_api.h with the same number of arguments."""
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "pt_api.h")).read(), flags=re.S)
+    decls = {}
+    for name, args in re.findall(r"\b(pt_[a-z_0-9]+)\s*\(([^;{]*?)\)\s*;", header, flags=re.S):
+        args = args.strip()
+        decls[name] = 0 if args in ("", "void") else args.count(",") + 1
+    stub = re.findall(r"pub fn (pt_[a-z_0-9]+)\s*\((.*?)\)\s*(?:->\s*[^;]+)?;", _rust_blocks(), flags=re.S)
+    assert len(stub) >= 15
+    for name, args in stub:
+        assert name in decls, name
+        n = len(re.findall(r"(?<!:):(?!:)", args))          # one `name: type` per argument (`::` is a path)
+        assert n == decls[name], (name, n, decls[name])

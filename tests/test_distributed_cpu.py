@@ -141,3 +141,57 @@ def test_two_rank_sharded_render_matches_single_rank(tmp_path, oracle_shared, sc
     # and it is the single-GPU running mean up to f32 rounding (tolerance: 2e-6 relative)
     mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
     np.testing.assert_allclose(r0[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)
+
+
+def _combine_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    from path_tracing_amd.distributed import combine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    # two INDEPENDENT one-rank renders inside a two-rank job: no collective, images stay apart.  Rank 1 does
+    # not even call combine() a second time, which would hang rank 0 if a collective were issued.
+    mine = torch.full((4,), float(rank + 1))
+    res["alone_ran"] = combine(mine, 1)
+    res["alone"] = mine.tolist()
+    if rank == 0:
+        extra = torch.full((4,), 7.0)
+        combine(extra, 1, collective="reduce")
+        res["extra"] = extra.tolist()
+    # a render sharded over both ranks: one sum
+    both = torch.full((4,), float(rank + 1))
+    res["both_ran"] = combine(both, 2)
+    res["both"] = both.tolist()
+    # world size that disagrees with the group
+    try:
+        combine(torch.zeros(4), 3)
+        res["mismatch"] = "no error"
+    except ValueError as e:
+        res["mismatch"] = str(e)
+    # a one-rank SUBGROUP with the collective forced (what the one-GPU RCCL rehearsal does)
+    groups = [dist.new_group([r]) for r in range(world)]
+    solo = torch.full((4,), float(10 * (rank + 1)))
+    res["solo_ran"] = combine(solo, 1, group=groups[rank], collective="reduce", force_collective=True)
+    res["solo"] = solo.tolist()
+    np.save(os.path.join(out_dir, "combine%d.npy" % rank), np.array([repr(res)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_renderers_in_a_larger_job_do_not_talk(tmp_path, pkg):
+    """ShardedRenderer's collective step (distributed.combine): world_size 1 issues no collective on the job's default
+    group; world_size must equal the group's size; a forced one-rank collective stays inside its own group."""
+    import torch.multiprocessing as mp
+    mp.spawn(_combine_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [eval(str(np.load(tmp_path / ("combine%d.npy" % k))[0])) for k in range(2)]
+    for k in range(2):
+        assert r[k]["alone_ran"] is False and r[k]["alone"] == [float(k + 1)] * 4
+        assert r[k]["both_ran"] is True and r[k]["both"] == [3.0] * 4
+        assert "sharded over 3 ranks but the process group has 2" in r[k]["mismatch"]
+        assert r[k]["solo_ran"] is True and r[k]["solo"] == [10.0 * (k + 1)] * 4
+    assert r[0]["extra"] == [7.0] * 4

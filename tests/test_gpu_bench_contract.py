@@ -67,3 +67,24 @@ def test_bench_under_the_launcher_with_a_one_rank_rccl_group(shard):
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["path_ms_per_step"] > 0
     assert d["collective_ms_per_step"] >= 0 and "predicted_efficiency" in d
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (as a child,
+    before it has touched the GPU) and passes the one JSON line through.  A one-GPU box cannot hold two RCCL ranks, so
+    both ranks share GPU 0 and talk over gloo here (PT_BENCH_REHEARSAL=1: the code path, not the numbers)."""
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank"]) == 2
+    assert sorted(p["rank"] for p in d["per_rank"]) == [0, 1]
+    # the default for N > 1 times both splits; the line's value is the frame split's (samples per pixel split over GPUs)
+    assert set(d["splits"]) == {"frames", "pixels"} and d["value"] == d["splits"]["frames"]["value"]
+    assert "samples per pixel split" in d["config"]["parallelism"]
+    assert all(len(s["per_rank"]) == 2 for s in d["splits"].values())

@@ -79,7 +79,7 @@ def _rccl_worker(rank, port, n_frames, out_dir):
         with pkg.Renderer(p, device=0) as r:
             r.upload_scene(scenes.spheres_for("cfg1"), tris, bvh)
             r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
-            sh = ShardedRenderer(r, 0, 1, mode=mode, collective=collective)
+            sh = ShardedRenderer(r, 0, 1, mode=mode, collective=collective, force_collective=True)
             sh.render(0, n_frames)
             np.save(os.path.join(out_dir, "%s_%s.npy" % (mode, collective)), sh.image().cpu().numpy())
     t = torch.tensor([1.5], dtype=torch.float64, device="cuda")

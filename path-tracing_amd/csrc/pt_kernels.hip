@@ -157,13 +157,27 @@ __device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y) {
     return mk2(n.x / b.x, n.y / b.y);
 }
 
-__device__ __forceinline__ float box_result(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz) {
+/* t_near, t_far of the slab test (shader.wgsl:244-250) */
+__device__ __forceinline__ void box_near_far(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz,
+                                             float &t_near, float &t_far) {
     float t1x = fmin_(tminx, tmaxx), t1y = fmin_(tminy, tmaxy), t1z = fmin_(tminz, tmaxz);
     float t2x = fmax_(tminx, tmaxx), t2y = fmax_(tminy, tmaxy), t2z = fmax_(tminz, tmaxz);
-    float t_near = fmax_(fmax_(t1x, t1y), t1z);
-    float t_far = fmin_(fmin_(t2x, t2y), t2z);
-    bool did_hit = (t_near <= t_far) && (t_far >= 0.0f);
-    return did_hit ? t_near : PT_BOX_MISS;
+    t_near = fmax_(fmax_(t1x, t1y), t1z);
+    t_far = fmin_(fmin_(t2x, t2y), t2z);
+}
+/* Conditions as lane masks in scalar registers: the compare writes the mask, the logic on masks runs on the scalar
+ * unit, and in_mask() hands a mask back as a per-lane condition without a vector instruction.  (Written as `bool`
+ * selects, the compiler turns such logic into 0/1 values in vector registers.) */
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask lanes_where(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+__device__ __forceinline__ bool in_mask(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
+/* did_hit of ray_box, shader.wgsl:252 */
+__device__ __forceinline__ bool box_hit(float t_near, float t_far) { return (t_near <= t_far) & (t_far >= 0.0f); }
+__device__ __forceinline__ float box_result(float tminx, float tminy, float tminz, float tmaxx, float tmaxy, float tmaxz) {
+    float t_near, t_far;
+    box_near_far(tminx, tminy, tminz, tmaxx, tmaxy, tmaxz, t_near, t_far);
+    return box_hit(t_near, t_far) ? t_near : PT_BOX_MISS;
 }
 
 /* The ray as the box test wants it: x and y ride together in packed instructions, z is
@@ -172,16 +186,25 @@ struct RayPk { f2 oxy, ozz, dxy, dzz, yxy, yzz; };
 
 /* q0 = (A.min.x, A.min.y, A.max.x, A.max.y)  q1 = (B.min.x, B.min.y, B.max.x, B.max.y)
  * q2 = (A.min.z, A.max.z, B.min.z, B.max.z) */
+struct Box2 { float near_a, far_a, near_b, far_b; };      /* t_near / t_far of the two children's slab tests */
 template <bool FAST>
-__device__ __forceinline__ void ray_box2(const RayPk &R, float4 q0, float4 q1, float4 q2, float &dst_a, float &dst_b) {
+__device__ __forceinline__ Box2 ray_box2_nf(const RayPk &R, float4 q0, float4 q1, float4 q2) {
     f2 a_min = div2<FAST>(mk2(q0.x, q0.y) - R.oxy, R.dxy, R.yxy);
     f2 a_max = div2<FAST>(mk2(q0.z, q0.w) - R.oxy, R.dxy, R.yxy);
     f2 b_min = div2<FAST>(mk2(q1.x, q1.y) - R.oxy, R.dxy, R.yxy);
     f2 b_max = div2<FAST>(mk2(q1.z, q1.w) - R.oxy, R.dxy, R.yxy);
     f2 a_z = div2<FAST>(mk2(q2.x, q2.y) - R.ozz, R.dzz, R.yzz);
     f2 b_z = div2<FAST>(mk2(q2.z, q2.w) - R.ozz, R.dzz, R.yzz);
-    dst_a = box_result(a_min.x, a_min.y, a_z.x, a_max.x, a_max.y, a_z.y);
-    dst_b = box_result(b_min.x, b_min.y, b_z.x, b_max.x, b_max.y, b_z.y);
+    Box2 r;
+    box_near_far(a_min.x, a_min.y, a_z.x, a_max.x, a_max.y, a_z.y, r.near_a, r.far_a);
+    box_near_far(b_min.x, b_min.y, b_z.x, b_max.x, b_max.y, b_z.y, r.near_b, r.far_b);
+    return r;
+}
+template <bool FAST>
+__device__ __forceinline__ void ray_box2(const RayPk &R, float4 q0, float4 q1, float4 q2, float &dst_a, float &dst_b) {
+    const Box2 b = ray_box2_nf<FAST>(R, q0, q1, q2);
+    dst_a = box_hit(b.near_a, b.far_a) ? b.near_a : PT_BOX_MISS;
+    dst_b = box_hit(b.near_b, b.far_b) ? b.near_b : PT_BOX_MISS;
 }
 
 /* may this lane's ray use the reciprocal form?  (scene-side condition: P.fast_div) */
@@ -339,41 +362,25 @@ __device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveM
     float4 q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
     float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
     const uint2 refs = make_uint2(w3.x, w3.y);
-    float dst_a, dst_b;
-    ray_box2<FAST>(T.R, q0, q1, q2, dst_a, dst_b);
-#ifdef PT_ABL_DIV2      /* sensitivity probe: a second box test whose result cannot change anything */
-    {
-        float xa, xb;
-        float4 p0 = q0, p1 = q1, p2 = q2;
-        asm volatile("" : "+v"(p0.x), "+v"(p0.y), "+v"(p0.z), "+v"(p0.w), "+v"(p1.x), "+v"(p1.y), "+v"(p1.z), "+v"(p1.w),
-                          "+v"(p2.x), "+v"(p2.y), "+v"(p2.z), "+v"(p2.w));       /* all twelve planes opaque: nothing of the first test can be reused */
-        ray_box2<FAST>(T.R, p0, p1, p2, xa, xb);
-        dst_a = fmin_(dst_a, fabsf(xa) + 3.0e38f);
-        dst_b = fmin_(dst_b, fabsf(xb) + 3.0e38f);
-    }
-#endif
-#ifdef PT_ABL_LOAD2     /* sensitivity probe: four more 16-byte loads, PT_ABL_LOAD2 records back */
-    {
-#ifdef PT_ABL_LOAD2_UNIFORM     /* the same record for all lanes, still through the vector path */
-        uint32_t first_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.cur);
-        asm volatile("v_mov_b32 %0, %1" : "=v"(first_cur) : "s"(first_cur));
-        const PTInnerRecord *r2 = P.inner + first_cur;
-#else
-        const PTInnerRecord *r2 = P.inner + (T.cur >= PT_ABL_LOAD2 ? T.cur - PT_ABL_LOAD2 : T.cur);
-#endif
-        float4 e0 = r2->q[0], e1 = r2->q[1], e2 = r2->q[2], e3 = r2->q[3];
-        float s = e0.x + e1.x + e2.x + e3.x;
-        dst_a = fmin_(dst_a, fabsf(s) + 3.0e38f);
-    }
-#endif
+    const Box2 bx = ray_box2_nf<FAST>(T.R, q0, q1, q2);
     if (COUNT) cn.boxes += 2;
-    uint32_t ref_a = refs.x, ref_b = refs.y;
-    float dst_near, dst_far;
-    uint32_t ref_near, ref_far;
-    if (dst_a < dst_b) { dst_near = dst_a; dst_far = dst_b; ref_near = ref_a; ref_far = ref_b; }
-    else               { dst_near = dst_b; dst_far = dst_a; ref_near = ref_b; ref_far = ref_a; }
-    if (dst_far < T.best_t) stack_push<SPILL>(M, T, ref_far);
-    T.cur = (dst_near < T.best_t) ? ref_near : PT_REF_NONE;
+    const uint32_t ref_a = refs.x, ref_b = refs.y;
+    /* did_hit of ray_box, shader.wgsl:252, as lane masks */
+    const lanemask m_hit_a = lanes_where(bx.near_a <= bx.far_a) & lanes_where(bx.far_a >= 0.0f);
+    const lanemask m_hit_b = lanes_where(bx.near_b <= bx.far_b) & lanes_where(bx.far_b >= 0.0f);
+    /* shader.wgsl:205-230 with ray_box's result (`did_hit ? t_near : 999999999.0`) never materialised.  A missed box
+     * is never visited: its 999999999.0 is not below a best distance that starts at far_distance <= 999999999.0
+     * (pt_create refuses larger values) and only shrinks.  So "may be visited" is hit & (t_near < best), and which
+     * of the two boxes is "near" matters only when both may be visited; then both were hit and `dst_a < dst_b` is
+     * t_near_a < t_near_b.  The conditions stay lane masks (scalar logic); the vector ALU does seven compares. */
+    const lanemask m_ok_a = m_hit_a & lanes_where(bx.near_a < T.best_t), m_ok_b = m_hit_b & lanes_where(bx.near_b < T.best_t);
+    const lanemask m_a_near = m_hit_a & (~m_hit_b | lanes_where(bx.near_a < bx.near_b));
+    const bool a_near = in_mask(m_a_near);
+    const bool go_near = in_mask((m_a_near & m_ok_a) | (~m_a_near & m_ok_b));
+    const bool push_far = in_mask((m_a_near & m_ok_b) | (~m_a_near & m_ok_a));
+    const uint32_t ref_near = a_near ? ref_a : ref_b, ref_far = a_near ? ref_b : ref_a;
+    if (push_far) stack_push<SPILL>(M, T, ref_far);
+    T.cur = go_near ? ref_near : PT_REF_NONE;
 }
 
 /* compare-exchange of two (distance, reference) pairs: afterwards da <= db */
@@ -458,7 +465,7 @@ template <bool FAST, bool COUNT, bool SPILL, bool WIDE = false>
 __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, bool traversing,
                                                Trav &T, Counters &cn, WaveStats *ws = nullptr, int leaf_turn = -1) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
-    const bool is_inner = traversing && !is_leaf;
+    bool is_inner = traversing && !is_leaf;
     const unsigned long long inner_mask = __ballot(is_inner);
     const unsigned long long leaf_mask = __ballot(is_leaf);
     const uint32_t n_leaf = (uint32_t)__popcll(leaf_mask), n_inner = (uint32_t)__popcll(inner_mask);
@@ -466,21 +473,24 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
     if (leaf_turn < 0) run_leaves = !inner_mask || n_leaf >= P.leaf_min || (n_leaf << P.leaf_shift) >= n_leaf + n_inner;
     else run_leaves = leaf_turn > 0 && leaf_mask;       /* the path kernel gives leaves fixed turns */
     bool done = false;
+    /* In a leaf turn the leaves go first: a lane that pops an inner node after its leaf visits that node in this
+     * same step, together with the lanes that stood at an inner node anyway (one step saved per leaf visit). */
+    if (run_leaves) {
+        if (is_leaf) {
+            leaf_visit<COUNT>(P, T, cn);
+            done = trav_advance<SPILL>(M, T);
+            is_inner = !done && (T.cur & PT_REF_LEAF) == 0u;
+        }
+    }
     if (COUNT && ws) {
         ws->steps++;
-        ws->inner_lanes += (unsigned)__popcll(inner_mask);
+        ws->inner_lanes += (unsigned)__popcll(__ballot(is_inner));
         if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
     if (is_inner) {
         if (WIDE) wide_visit<FAST, SPILL>(P, M, T);
         else inner_visit<FAST, COUNT, SPILL>(P, M, T, cn);
         done = trav_advance<SPILL>(M, T);
-    }
-    if (run_leaves) {
-        if (is_leaf) {
-            leaf_visit<COUNT>(P, T, cn);
-            done = trav_advance<SPILL>(M, T);
-        }
     }
     return done;
 }

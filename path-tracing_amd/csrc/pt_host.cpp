@@ -116,6 +116,10 @@ struct pt_ctx {
     bool fast_div = false;
     uint32_t shard_rank = 0, shard_world = 1;
     uint32_t refill_min = 60;
+    uint32_t quad_fetch = 0;           /* PT_QUAD_FETCH: see PTKernelParams::quad_fetch */
+    uint32_t two_paths = 0;            /* PT_TWO_PATHS: see PTKernelParams::two_paths */
+    uint32_t starve_min = 16;
+    float4 *d_pathbuf = nullptr;
     uint32_t leaf_min = 8;
     uint32_t leaf_shift = 2;
 
@@ -439,6 +443,11 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     }
     k.fast_div = c->fast_div ? 1u : 0u;
     k.refill_min = c->refill_min;
+    k.quad_fetch = c->quad_fetch;
+    k.two_paths = (c->two_paths && c->d_pathbuf && !c->d_wide) ? 1u : 0u;
+    k.starve_min = c->starve_min;
+    k.pathbuf = c->d_pathbuf;
+    k.pathbuf_bytes = (uint32_t)pt_pathbuf_bytes(c->num_cus);
     k.leaf_min = c->leaf_min;
     k.leaf_shift = c->leaf_shift;
     k.xcd_queues = getenv("PT_NO_XCD_QUEUES") ? 0u : 1u;
@@ -678,6 +687,9 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->params = *params;
     { std::lock_guard<std::mutex> lock(g_static_scratch_mutex); c->serial = g_next_serial++; }
     if (const char *e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_min = (uint32_t)v; }
+    if (const char *e = getenv("PT_QUAD_FETCH")) c->quad_fetch = atoi(e) != 0;
+    if (const char *e = getenv("PT_TWO_PATHS")) c->two_paths = atoi(e) != 0;
+    if (const char *e = getenv("PT_STARVE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->starve_min = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 6) c->leaf_shift = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }
     auto bail = [&](hipError_t he, const char *what) {
@@ -719,6 +731,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if ((e = hipHostMalloc((void **)&c->h_hit_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(hit count)");
     if ((e = hipMalloc(&c->d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pixel_hit)");
     if ((e = hipMalloc(&c->d_pixel_const, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(pixel_const)");
+    if (c->two_paths && (e = hipMalloc(&c->d_pathbuf, pt_pathbuf_bytes(c->num_cus))) != hipSuccess) return bail(e, "hipMalloc(pathbuf)");
     if ((e = hipMalloc(&c->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
     if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
@@ -1170,7 +1183,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_wide);
     dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
-    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill);
+    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill); dev_free(c->d_pathbuf);
     dev_free(c->d_refit_order); dev_free(c->d_tri9); dev_free(c->d_refit_flag);
     if (c->h_hit_count) (void)hipHostFree(c->h_hit_count);
     if (c->stream) (void)hipStreamDestroy(c->stream);

@@ -93,6 +93,11 @@ struct PTKernelParams {
     uint32_t leaf_min;             /* lanes that must be at a leaf before the triangle code runs (see trav_wave_step) */
     uint32_t leaf_shift;           /* ... or when they are at least 1/2^leaf_shift of the traversing lanes */
     uint32_t refill_min;           /* path kernel: lanes that must wait for shading before the wave leaves the traversal loop */
+    uint32_t two_paths;            /* path kernel: two paths per lane, state in `pathbuf` (path_kernel_mb) */
+    uint32_t starve_min;           /* ... a round also runs when this many lanes have nothing to walk and a buffer to shade */
+    float4 *pathbuf;               /* two-paths-per-lane state: pt_pathbuf_bytes() */
+    uint32_t pathbuf_bytes;
+    uint32_t quad_fetch;           /* path kernel: the four lanes of a quad fetch each other's inner records (one cache line per gather and quad) */
     uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;
     uint32_t tris_bytes;           /* size of the triangle-record array (at most 2^24 x 48 bytes) */
@@ -134,5 +139,6 @@ hipError_t pt_launch_refit_level(PTInnerRecord *inner, const uint32_t *order, ui
 int pt_max_stack_entries(void);
 uint32_t pt_lane_stride(int num_cus);   /* upper bound of the path kernel's grid size in lanes */
 uint32_t pt_spill_entries(uint32_t stack_entries);
+size_t pt_pathbuf_bytes(int num_cus);   /* size of PTKernelParams::pathbuf */
 
 #endif

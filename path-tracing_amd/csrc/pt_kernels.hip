@@ -141,6 +141,8 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 mk2(float a, float b) { f2 r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ float4 u4_as_f4(u4_t w) { return make_float4(__uint_as_float(w.x), __uint_as_float(w.y), __uint_as_float(w.z), __uint_as_float(w.w)); }
+__device__ __forceinline__ u4_t f4_as_u4(float4 v) { u4_t w; w.x = __float_as_uint(v.x); w.y = __float_as_uint(v.y); w.z = __float_as_uint(v.z); w.w = __float_as_uint(v.w); return w; }
 
 template <bool FAST>
 __device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y) {
@@ -315,9 +317,11 @@ extern __shared__ uint32_t pt_lds[];
 __device__ __forceinline__ uint32_t lane_id();
 
 struct WaveMem {
+    uint32_t xchg;          /* byte offset in pt_lds of this wave's record exchange area (quad fetch only; wave-uniform) */
     uint32_t base;          /* byte offset in pt_lds of this wave's stack rows (wave-uniform) */
     uint32_t limit;         /* base + 256 * entries kept in LDS (wave-uniform); deeper entries go to `spill` */
-    uint32_t *spill;        /* this lane's overflow column in global memory (SPILL variants only) */
+    uint32_t *spill;        /* overflow entries in global memory (SPILL variants only; wave-uniform) */
+    uint32_t spill_lane;    /* this lane's column there */
     uint32_t spill_stride;
 };
 
@@ -333,7 +337,7 @@ __device__ __forceinline__ uint32_t *lds_word(uint32_t byte_offset) {
 template <bool SPILL>
 __device__ __forceinline__ void stack_push(const WaveMem &M, Trav &T, uint32_t v) {
     if (!SPILL || T.sp < M.limit) *lds_word(T.sp) = v;
-    else M.spill[((T.sp - M.limit) >> 8) * M.spill_stride] = v;
+    else M.spill[((T.sp - M.limit) >> 8) * M.spill_stride + M.spill_lane] = v;
     T.sp += 256u;
 }
 
@@ -344,24 +348,81 @@ __device__ __forceinline__ bool trav_advance(const WaveMem &M, Trav &T) {
     if (stack_empty(M, T)) return true;
     T.sp -= 256u;
     if (!SPILL || T.sp < M.limit) T.cur = *lds_word(T.sp);
-    else T.cur = M.spill[((T.sp - M.limit) >> 8) * M.spill_stride];
+    else T.cur = M.spill[((T.sp - M.limit) >> 8) * M.spill_stride + M.spill_lane];
     return false;
 }
 
-template <bool FAST, bool COUNT, bool SPILL>
-__device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, Trav &T, Counters &cn) {
-    /* buffer loads: scalar base + 32-bit offset (no 64-bit address arithmetic per lane), and a record index
-     * outside the array reads zeros instead of faulting */
+/*
+ * Quad fetch of the inner records.  A 64-lane gather of 16 bytes per lane costs the CU's address unit 16 cycles
+ * plus about 0.6 for every cache line beyond one per quad of lanes, and a visit needs four of them: with every
+ * lane fetching its own record that is 4 x 44 cycles for 64 unrelated records, with the four lanes of a quad
+ * fetching each other's records it is 4 x 16.  Gather k reads the record of the quad's lane k, one 16-byte piece
+ * per lane (four lanes, one line), straight into LDS: buffer_load_dwordx4 ... lds puts lane l's piece at M0 + 16 l,
+ * so the record of quad g's lane k is the 64 bytes at area k + 64 g, and every lane reads its own record back with
+ * ds_read_b128.  The four areas are 1040 bytes apart, so that the four lanes of a quad read from different banks.
+ * Lanes without an inner node pass an offset beyond the array: the buffer descriptor returns zeros for those
+ * without touching memory.  All 64 lanes of the wave must call quad_fetch together.
+ */
+#define PT_XCHG_AREA 1040u
+#define PT_XCHG_BYTES (4u * PT_XCHG_AREA)
+#define PT_NO_RECORD_OFFSET 0xffffffc0u     /* past the end of any inner-record array (the upload refuses 2^26 records) */
+#define PT_DPP_QUAD_LANE(k) ((k) * 0x55)
+
+/* Where the calling lane finds its own record: area (lane & 3), quad (lane >> 2) = xchg + 16 lane + 1024 (lane & 3).
+ * Worked out from the lane number where it is needed (five instructions): kept in a register across the kernel it
+ * ends up in scratch memory, one more vector-memory instruction per step. */
+__device__ __forceinline__ uint32_t quad_fetch_own(const WaveMem &M) {
+    uint32_t lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+    const uint32_t t = lane * 16u + M.xchg;            /* xchg is a multiple of 64 */
+    return ((t & 0x30u) << 6) + t;
+}
+
+__device__ __forceinline__ void quad_fetch(const PTKernelParams &P, const WaveMem &M, uint32_t own, uint32_t record_offset) {
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.inner, 0, (int)P.inner_bytes, 0x00020000);
-    const uint32_t off = T.cur * 64u;
-    const u4_t w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-    const u4_t w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
-    const u4_t w2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
-    const u2_t w3 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 48u, 0, 0);
-    float4 q0 = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
-    float4 q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
-    float4 q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
-    const uint2 refs = make_uint2(w3.x, w3.y);
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    char *area = (char *)pt_lds + M.xchg;
+    const uint32_t piece = own & 0x30u;         /* 16 x the lane's place in its quad: the 16 bytes of a record this lane fetches */
+    const uint32_t a0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)record_offset, PT_DPP_QUAD_LANE(0), 0xf, 0xf, true) + piece;
+    const uint32_t a1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)record_offset, PT_DPP_QUAD_LANE(1), 0xf, 0xf, true) + piece;
+    const uint32_t a2 = (uint32_t)__builtin_amdgcn_mov_dpp((int)record_offset, PT_DPP_QUAD_LANE(2), 0xf, 0xf, true) + piece;
+    const uint32_t a3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)record_offset, PT_DPP_QUAD_LANE(3), 0xf, 0xf, true) + piece;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(area), 16, a0, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(area + PT_XCHG_AREA), 16, a1, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(area + 2u * PT_XCHG_AREA), 16, a2, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(area + 3u * PT_XCHG_AREA), 16, a3, 0, 0, 0);
+}
+
+/* the calling lane's record, once the gathers of quad_fetch have landed */
+__device__ __forceinline__ void quad_fetch_read(uint32_t own_offset, float4 &q0, float4 &q1, float4 &q2, uint2 &refs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char *own = (const char *)pt_lds + own_offset;
+    q0 = *(const float4 *)(own);
+    q1 = *(const float4 *)(own + 16);
+    q2 = *(const float4 *)(own + 32);
+    refs = *(const uint2 *)(own + 48);
+}
+
+template <bool FAST, bool COUNT, bool SPILL, bool COOP = false>
+__device__ __forceinline__ void inner_visit(const PTKernelParams &P, const WaveMem &M, Trav &T, Counters &cn, uint32_t own = 0) {
+    float4 q0, q1, q2;
+    uint2 refs;
+    if (COOP) {
+        quad_fetch_read(own, q0, q1, q2, refs);       /* the wave has called quad_fetch */
+    } else {
+        /* buffer loads: scalar base + 32-bit offset (no 64-bit address arithmetic per lane), and a record index
+         * outside the array reads zeros instead of faulting */
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)P.inner, 0, (int)P.inner_bytes, 0x00020000);
+        const uint32_t off = T.cur * 64u;
+        const u4_t w0 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+        const u4_t w1 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 16u, 0, 0);
+        const u4_t w2 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + 32u, 0, 0);
+        const u2_t w3 = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 48u, 0, 0);
+        q0 = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+        q1 = make_float4(__uint_as_float(w1.x), __uint_as_float(w1.y), __uint_as_float(w1.z), __uint_as_float(w1.w));
+        q2 = make_float4(__uint_as_float(w2.x), __uint_as_float(w2.y), __uint_as_float(w2.z), __uint_as_float(w2.w));
+        refs = make_uint2(w3.x, w3.y);
+    }
     const Box2 bx = ray_box2_nf<FAST>(T.R, q0, q1, q2);
     if (COUNT) cn.boxes += 2;
     const uint32_t ref_a = refs.x, ref_b = refs.y;
@@ -461,7 +522,7 @@ struct WaveStats { unsigned long long steps, inner_lanes, leaf_lanes, leaf_runs;
  * lane computes (its own visit order is the shader's); it keeps the triangle code from running for
  * one or two lanes in every step.  Returns true for lanes whose traversal completed in this step.
  */
-template <bool FAST, bool COUNT, bool SPILL, bool WIDE = false>
+template <bool FAST, bool COUNT, bool SPILL, bool WIDE = false, bool COOP = false>
 __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const WaveMem &M, bool traversing,
                                                Trav &T, Counters &cn, WaveStats *ws = nullptr, int leaf_turn = -1) {
     const bool is_leaf = traversing && (T.cur & PT_REF_LEAF) != 0u;
@@ -487,7 +548,16 @@ __device__ __forceinline__ bool trav_wave_step(const PTKernelParams &P, const Wa
         ws->inner_lanes += (unsigned)__popcll(__ballot(is_inner));
         if (run_leaves) { ws->leaf_runs++; ws->leaf_lanes += (unsigned)__popcll(leaf_mask); }
     }
-    if (is_inner) {
+    if (COOP && !WIDE) {
+        if (__ballot(is_inner)) {             /* wave-uniform: every lane takes part in the fetch */
+            const uint32_t own = quad_fetch_own(M);
+            quad_fetch(P, M, own, is_inner ? T.cur * 64u : PT_NO_RECORD_OFFSET);
+            if (is_inner) {
+                inner_visit<FAST, COUNT, SPILL, true>(P, M, T, cn, own);
+                done = trav_advance<SPILL>(M, T);
+            }
+        }
+    } else if (is_inner) {
         if (WIDE) wide_visit<FAST, SPILL>(P, M, T);
         else inner_visit<FAST, COUNT, SPILL>(P, M, T, cn);
         done = trav_advance<SPILL>(M, T);
@@ -654,7 +724,7 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     WaveMem M;                       /* the primary kernel keeps the whole stack in LDS */
     M.base = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave) * P.stack_entries * 256u;
-    M.limit = M.base + P.stack_entries * 256u; M.spill = nullptr; M.spill_stride = 0;
+    M.limit = M.base + P.stack_entries * 256u; M.spill = nullptr; M.spill_lane = 0; M.spill_stride = 0; M.xchg = 0;
     uint32_t px, py;
     if (AOV || P.shard_world <= 1u) {
         /* block = 16x16 pixels, wave = 8x8 tile (the ids/distance output always covers the whole image) */
@@ -734,19 +804,21 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
 #define PT_PATH_WAVES_PER_EU 6
 #endif
 #ifndef PT_STEPS_PER_CHECK
-#define PT_STEPS_PER_CHECK 9
+#define PT_STEPS_PER_CHECK 12
 #endif
 #ifndef PT_LEAF_PERIOD
 #define PT_LEAF_PERIOD 3
 #endif
 #define PT_PATH_OCCUPANCY __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES_PER_EU, PT_PATH_WAVES_PER_EU)))
-template <bool EXACT, bool COUNT, bool SPILL, bool WIDE = false>
+template <bool EXACT, bool COUNT, bool SPILL, bool WIDE = false, bool COOP = false>
 __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(PTKernelParams P, uint32_t lds_entries) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     WaveMem M;                       /* lds_entries stack entries per lane in LDS, deeper ones in global memory */
+    M.xchg = PT_PATH_WAVES_PER_BLOCK * lds_entries * 256u + wave * PT_XCHG_BYTES;     /* exchange areas follow the stacks */
     M.base = wave * lds_entries * 256u;
     M.limit = M.base + lds_entries * 256u;
-    M.spill = SPILL ? P.spill + (blockIdx.x * PT_PATH_BLOCK + threadIdx.x) : nullptr;
+    M.spill = SPILL ? P.spill : nullptr;
+    M.spill_lane = blockIdx.x * PT_PATH_BLOCK + threadIdx.x;
     M.spill_stride = P.spill_stride;
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
@@ -883,13 +955,13 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
              * on as soon as they are as many as the lanes still traversing */
             if (drained && n_wait >= (uint32_t)__popcll(trav_mask)) break;
 #pragma unroll
-            /* Several (nine) steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
+            /* Several (twelve) steps per pass: the two tests above cost a fifth of a step.  Every PT_LEAF_PERIOD-th
              * step also runs the triangle code for the lanes that stand at a leaf (they wait for it): measured
              * faster than deciding from lane counts in every step (2.98 -> 2.90 ms per frame). */
             for (int rep = 0; rep < PT_STEPS_PER_CHECK; rep++) {
                 const int turn = (rep % PT_LEAF_PERIOD) == PT_LEAF_PERIOD - 1 ? 1 : 0;
-                bool done = fast ? trav_wave_step<true, COUNT, SPILL, WIDE>(P, M, trav, T, cn, &ws, turn)
-                                 : trav_wave_step<false, COUNT, SPILL, WIDE>(P, M, trav, T, cn, &ws, turn);
+                bool done = fast ? trav_wave_step<true, COUNT, SPILL, WIDE, COOP>(P, M, trav, T, cn, &ws, turn)
+                                 : trav_wave_step<false, COUNT, SPILL, WIDE, COOP>(P, M, trav, T, cn, &ws, turn);
                 if (done) { trav = false; hit = true; }
             }
         }
@@ -923,6 +995,243 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
             atomicMax(&P.counters[23], rt_end);
         }
     }
+}
+
+/* ======================= bounces, two paths per lane ======================= */
+/*
+ * The same work as path_kernel under another schedule.  A lane owns TWO paths.  Their state (ray origin and
+ * direction, random seed, radiance so far, the sphere hit of the current ray, the result of the last cast) lives in
+ * a per-lane buffer pair in global memory; one path at a time is "walked": its ray sits in the lane's registers and
+ * runs through the tree.  Every PT_MB_SERVICE steps a lane whose cast is complete writes the hit back (8 bytes; that
+ * buffer now waits for shading) and takes up its other path if that one has a ray ready - the ready ray of the
+ * parked path waits in registers too (nine values), because a load from the buffers at every service point stalls
+ * the wave for a trip to the Infinity Cache.  The wave shades when P.refill_min lanes have a waiting buffer: one
+ * buffer per lane and round, through the same code as path_kernel's round (closest hit, sky or bounce, new path
+ * from the queue, sphere pass of the new ray).  So a round still runs with most lanes busy, but a lane does not sit
+ * idle from the end of its cast to the next round: 53 of 64 lanes do an inner-node visit per step instead of 41
+ * (tools/sim/block_sim.c, sim_multibuf, on recorded paths of the benchmark scene).
+ *
+ * Buffer of one path: five 16-byte quads, quad q of buffer b of lane l of wave w at
+ * pathbuf[((w * 2 + b) * 5 + q) * 64 + l], so that a wave's accesses are whole 1-KiB rows:
+ *   q0 = o.x o.y o.z i     q1 = d.x d.y d.z seed      q2 = light.xyz slot
+ *   q3 = ray_color.xyz sph_t                          q4 = sph_id best_t best_id -
+ */
+#ifndef PT_MB_SERVICE
+#define PT_MB_SERVICE 3
+#endif
+#define PT_MB_QUADS 5
+
+template <bool EXACT, bool COUNT, bool SPILL, bool COOP>
+__global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_mb(PTKernelParams P, uint32_t lds_entries) {
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    WaveMem M;
+    M.xchg = PT_PATH_WAVES_PER_BLOCK * lds_entries * 256u + wave * PT_XCHG_BYTES;
+    M.base = wave * lds_entries * 256u;
+    M.limit = M.base + lds_entries * 256u;
+    M.spill = SPILL ? P.spill : nullptr;
+    M.spill_lane = blockIdx.x * PT_PATH_BLOCK + threadIdx.x;
+    M.spill_stride = P.spill_stride;
+    const uint32_t rpp = P.rays_per_pixel;
+    const uint32_t per_hit = P.batch_frames * rpp;
+    const uint32_t total = P.ctrl->hit_count * per_hit;
+    const uint32_t part = ((P.ctrl->hit_count + 7u) / 8u) * per_hit;     /* whole pixels per part */
+    uint32_t queue = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
+    uint32_t queues_done = 0;
+    Counters cn = {0, 0, 0, 0};
+    /* this lane's two buffers: quad q of buffer b at byte mb_off + (b * 6 + q) * 1024 of pathbuf (buffer
+     * instructions: descriptor in scalar registers, one 32-bit offset per lane) */
+    const __amdgpu_buffer_rsrc_t mb = __builtin_amdgcn_make_buffer_rsrc((void *)P.pathbuf, 0, (int)P.pathbuf_bytes, 0x00020000);
+    const uint32_t mb_off = (blockIdx.x * PT_PATH_WAVES_PER_BLOCK + wave) * (2u * PT_MB_QUADS * 1024u) + lane_id() * 16u;
+#define MB_LOAD(off, q) u4_as_f4(__builtin_amdgcn_raw_buffer_load_b128(mb, (off), (q) * 1024, 0))
+#define MB_STORE(off, q, v) __builtin_amdgcn_raw_buffer_store_b128(f4_as_u4(v), mb, (off), (q) * 1024, 0)
+
+    bool drained = total == 0;
+    bool walking = false;       /* a cast is in progress in the lane's registers */
+    bool finished = false;      /* ... and is complete: to be written back at the next service point */
+    bool act1 = false;          /* which buffer is being walked */
+    /* per buffer: it holds a ray that has not been cast / it waits for a shading round / it holds no path yet */
+    bool ready0 = false, ready1 = false, wait0 = true, wait1 = true, fresh0 = true, fresh1 = true;
+    V3 park_o = mk(0, 0, 0), park_d = mk(0, 0, -1), park_y = mk(0, 0, -1);     /* the ready ray of the path that is not walked */
+    bool park_safe = false;
+    Trav T;
+    T.cur = PT_REF_NONE; T.sp = 0; T.best_t = P.far_distance; T.best_id = PT_NONE;
+    raypk_set(T.R, mk(0, 0, 0), mk(0, 0, -1));
+    bool safe = false;
+    WaveStats ws = {0, 0, 0, 0};
+    unsigned long long t_start = 0, t_trav = 0, outer_iters = 0, shade_lanes = 0, t_drained = 0;
+    unsigned long long rt_start = 0, rt_drained = 0;
+    if (COUNT) { t_start = __builtin_amdgcn_s_memtime(); rt_start = wall_clock64(); }
+
+    for (;;) {
+        /* ---- service point: write finished casts back, take up ready rays ---- */
+        if (__ballot(finished)) {
+            if (finished) {
+                u2_t r; r.x = __float_as_uint(T.best_t); r.y = (uint32_t)T.best_id;
+                __builtin_amdgcn_raw_buffer_store_b64(r, mb, mb_off + (act1 ? PT_MB_QUADS * 1024u : 0u), 4 * 1024 + 4, 0);
+                if (act1) wait1 = true; else wait0 = true;
+                finished = false;
+            }
+        }
+        const bool pick = !walking && (ready0 || ready1);
+        if (__ballot(pick)) {
+            if (pick) {
+                act1 = !ready0;
+                T.R.oxy = mk2(park_o.x, park_o.y); T.R.ozz = mk2(park_o.z, park_o.z);
+                T.R.dxy = mk2(park_d.x, park_d.y); T.R.dzz = mk2(park_d.z, park_d.z);
+                T.R.yxy = mk2(park_y.x, park_y.y); T.R.yzz = mk2(park_y.z, park_y.z);
+                safe = park_safe;
+                trav_begin(P, stack_bottom(M), T);
+                if (act1) ready1 = false; else ready0 = false;
+                walking = true;
+                if (COUNT) cn.casts++;
+            }
+        }
+        /* ---- shade? ---- */
+        const bool waiting = wait0 || wait1;
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot(waiting)), n_walk = (uint32_t)__popcll(__ballot(walking));
+        if (!n_wait && !n_walk) break;           /* every buffer of every lane is empty (ready rays were just taken up) */
+        const uint32_t n_starve = (uint32_t)__popcll(__ballot(waiting && !walking));
+        if (n_wait && (n_wait >= P.refill_min || n_starve >= P.starve_min || !n_walk || (drained && n_wait >= n_walk))) {
+            if (COUNT) { outer_iters++; shade_lanes += n_wait; }
+            const bool sb1 = !wait0;             /* the buffer this lane shades in this round */
+            const uint32_t b = mb_off + (sb1 ? PT_MB_QUADS * 1024u : 0u);
+            bool hit = false, idle = false, has_ray = false, emptied = false;
+            V3 ro = mk(0, 0, 0), rd = mk(0, 0, -1), light = mk(0, 0, 0), ray_color = mk(1, 1, 1);
+            uint32_t seed = 0, i = 0, slot = 0;
+            float hit_t = P.far_distance;
+            int32_t hit_id = PT_NONE;
+            if (waiting) {
+                if (sb1 ? fresh1 : fresh0) idle = true;
+                else {
+                    const float4 q0 = MB_LOAD(b, 0), q1 = MB_LOAD(b, 1), q3 = MB_LOAD(b, 2), q4 = MB_LOAD(b, 3), q5 = MB_LOAD(b, 4);
+                    ro = mk(q0.x, q0.y, q0.z); rd = mk(q1.x, q1.y, q1.z);
+                    seed = __float_as_uint(q1.w); i = __float_as_uint(q0.w); slot = __float_as_uint(q3.w);
+                    light = mk(q3.x, q3.y, q3.z); ray_color = mk(q4.x, q4.y, q4.z);
+                    /* (A) the closest hit of the finished cast: spheres win ties (shader.wgsl:144-160); a miss ends
+                     * the path with the sky term (shader.wgsl:128-132) */
+                    hit_t = q4.w; hit_id = __float_as_int(q5.x);
+                    const float best_t = q5.y;
+                    const int32_t best_id = __float_as_int(q5.z);
+                    if (best_id != PT_NONE && best_t < hit_t) { hit_t = best_t; hit_id = best_id; }
+                    if (hit_id == PT_NONE) {
+                        if (P.use_env) light = light + environment_light<EXACT>(P, rd) * ray_color;
+                        P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                        idle = true;
+                    } else hit = true;
+                }
+            }
+            /* (B) buffers without a path take one from the queue (see path_kernel) */
+            unsigned long long need = __ballot(idle);
+            if (need) {
+                while (!drained) {
+                    const uint32_t q_start = queue * part < total ? queue * part : total;
+                    const uint32_t q_len = (total - q_start < part) ? total - q_start : part;
+                    uint32_t base = 0;
+                    if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
+                    base = __shfl(base, 0, 64);
+                    const bool exhausted = base + (uint32_t)__popcll(need) >= q_len;
+                    if (base < q_len && idle) {
+                        const uint32_t local = base + prefix_count(need);
+                        if (local < q_len) {
+                            const uint32_t item = q_start + local;
+                            uint32_t hf = fast_div(item, P.div_rpp);
+                            uint32_t s = item - hf * rpp;
+                            uint32_t hi = fast_div(hf, P.div_batch);
+                            slot = sample_slot(hi, item - hi * per_hit, per_hit);
+                            uint32_t frame_count = P.frame_first + (hf - hi * P.batch_frames) * P.frame_stride;
+                            PTHitRecord h = P.hits[hi];
+                            uint32_t py = fast_div(h.pixel, P.div_width);
+                            uint32_t px = h.pixel - py * P.width;
+                            uint32_t pixel_index;
+                            primary_ray(P, px, py, rd, pixel_index);
+                            ro = ld3(P.cam_pos);
+                            seed = pixel_index + s * 248135u + frame_count * 393939123u;
+                            light = mk(0.0f, 0.0f, 0.0f);
+                            ray_color = mk(1.0f, 1.0f, 1.0f);
+                            i = 0;
+                            hit_t = h.distance; hit_id = h.prim_id;
+                            idle = false;
+                            hit = true;
+                        }
+                    }
+                    if (exhausted) {
+                        queue = (queue + 1u) & 7u;
+                        if (++queues_done == 8u) drained = true;
+                    }
+                    if (base < q_len) break;
+                }
+                if (drained && idle) { idle = false; emptied = true; }
+                if (COUNT && drained && !t_drained) { t_drained = __builtin_amdgcn_s_memtime(); rt_drained = wall_clock64(); }
+            }
+            /* one "hit" iteration of trace for old and new paths alike, shader.wgsl:119-127 */
+            if (hit) {
+                Surface sf = surface_of(P, ro, rd, hit_t, hit_id);
+                bounce<EXACT>(P, sf, seed, i, ro, rd, light, ray_color);
+                i++;
+                if (i > P.max_bounce_count) {                 /* loop bound reached: no sky term */
+                    P.samples[slot] = make_float4(light.x, light.y, light.z, 0.0f);
+                    idle = true;                              /* takes a new path in the next round */
+                } else has_ray = true;
+            }
+            /* the new ray: spheres first (shader.wgsl:144-154), reciprocals for the box test */
+            if (has_ray) {
+                float sph_t; int32_t sph_id;
+                spheres_closest(P, ro, rd, sph_t, sph_id);
+                park_safe = ray_div_safe(ro, rd);
+                park_o = ro; park_d = rd;
+                park_y = mk(1.0f / rd.x, 1.0f / rd.y, 1.0f / rd.z);
+                MB_STORE(b, 0, make_float4(ro.x, ro.y, ro.z, __uint_as_float(i)));
+                MB_STORE(b, 1, make_float4(rd.x, rd.y, rd.z, __uint_as_float(seed)));
+                MB_STORE(b, 2, make_float4(light.x, light.y, light.z, __uint_as_float(slot)));
+                MB_STORE(b, 3, make_float4(ray_color.x, ray_color.y, ray_color.z, sph_t));
+                __builtin_amdgcn_raw_buffer_store_b32((uint32_t)sph_id, mb, b, 4 * 1024, 0);
+            }
+            if (waiting) {
+                /* has_ray: ready.  idle: no path (stays waiting, takes one in the next round).  emptied: queue dry. */
+                if (sb1) { ready1 = has_ray; wait1 = idle; fresh1 = !has_ray; }
+                else     { ready0 = has_ray; wait0 = idle; fresh0 = !has_ray; }
+            }
+            (void)emptied;
+            continue;
+        }
+        /* ---- traverse ---- */
+        const bool fast = P.fast_div && __all(!walking || safe);
+        unsigned long long t0 = 0;
+        if (COUNT) t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll
+        for (int rep = 0; rep < PT_MB_SERVICE; rep++) {
+            const int turn = (rep % PT_LEAF_PERIOD) == PT_LEAF_PERIOD - 1 ? 1 : 0;
+            bool done = fast ? trav_wave_step<true, COUNT, SPILL, false, COOP>(P, M, walking, T, cn, &ws, turn)
+                             : trav_wave_step<false, COUNT, SPILL, false, COOP>(P, M, walking, T, cn, &ws, turn);
+            if (done) { walking = false; finished = true; }
+        }
+        if (COUNT) t_trav += __builtin_amdgcn_s_memtime() - t0;
+    }
+    if (COUNT) {
+        flush_counters(P, cn, 1ull, true);
+        if (lane_id() == 0) {
+            atomicAdd(&P.counters[8], __builtin_amdgcn_s_memtime() - t_start);
+            atomicAdd(&P.counters[9], t_trav);
+            atomicAdd(&P.counters[10], ws.steps);
+            atomicAdd(&P.counters[11], ws.inner_lanes);
+            atomicAdd(&P.counters[12], ws.leaf_lanes);
+            atomicAdd(&P.counters[13], ws.leaf_runs);
+            atomicAdd(&P.counters[14], outer_iters);
+            atomicAdd(&P.counters[15], shade_lanes);
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            if (!t_drained) t_drained = t_end;
+            atomicMax(&P.counters[16], t_end - t_start);
+            atomicMax(&P.counters[17], t_end - t_drained);
+            atomicAdd(&P.counters[20], t_end - t_drained);
+            const unsigned long long rt_end = wall_clock64();
+            if (!rt_drained) rt_drained = rt_end;
+            atomicMax(&P.counters[21], (1ull << 62) - rt_start);
+            atomicMax(&P.counters[22], (1ull << 62) - rt_drained);
+            atomicMax(&P.counters[23], rt_end);
+        }
+    }
+#undef MB_LOAD
+#undef MB_STORE
 }
 
 /* ======================= per-pixel resolve ======================= */
@@ -1053,9 +1362,12 @@ hipError_t pt_launch_probe(const PTKernelParams &kp, bool exact, const uint32_t 
 int pt_max_stack_entries(void) { return 64; }       /* 64 entries x 4 waves x 256 B = 64 KiB, the default dynamic-LDS limit */
 /* the persistent grid never exceeds 8 blocks per CU */
 uint32_t pt_lane_stride(int num_cus) { return (uint32_t)num_cus * 32u * 64u; }      /* at most 32 waves per CU */
+/* two buffers of PT_MB_QUADS quads per lane of the largest grid pt_launch_paths uses */
+size_t pt_pathbuf_bytes(int num_cus) { return (size_t)pt_lane_stride(num_cus) * 2u * PT_MB_QUADS * sizeof(float4); }
 
-#define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS when it spills */
-#define PT_PATH_LDS_ALL 30        /* deepest tree whose whole stack the path kernel keeps in LDS */
+#define PT_PATH_LDS_STACK 16      /* stack entries per lane the path kernel keeps in LDS when PT_FORCE_SPILL asks for a spilling stack */
+#define PT_PATH_LDS_ALL 30        /* deepest tree whose whole stack the path kernel keeps in LDS (own-record fetch) */
+#define PT_PATH_LDS_MIN 8         /* the fewest stack entries per lane the path kernel ever keeps in LDS */
 
 static size_t block_lds_bytes(uint32_t entries) {
     return (size_t)PT_WAVES_PER_BLOCK * (size_t)entries * 64 * sizeof(uint32_t);
@@ -1063,7 +1375,7 @@ static size_t block_lds_bytes(uint32_t entries) {
 
 /* stack entries per lane the path kernel spills to global memory, for sizing PTKernelParams::spill */
 uint32_t pt_spill_entries(uint32_t stack_entries) {
-    return stack_entries > PT_PATH_LDS_STACK ? stack_entries - PT_PATH_LDS_STACK : 0;     /* PT_FORCE_SPILL may ask for it */
+    return stack_entries > PT_PATH_LDS_MIN ? stack_entries - PT_PATH_LDS_MIN : 0;
 }
 
 hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, bool aov, hipStream_t st) {
@@ -1094,42 +1406,69 @@ hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact, bool count, b
     return hipGetLastError();
 }
 
-template <bool SPILL>
+template <bool SPILL, bool COOP>
 static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool count, dim3 grid, size_t lds, uint32_t lds_entries,
                                  hipStream_t st) {
     dim3 block(PT_PATH_BLOCK);
-    if (kp.wide) {
+    if (kp.wide) {          /* the four-wide walk fetches its own records */
         if (exact) hipLaunchKernelGGL((path_kernel<true, false, SPILL, true>), grid, block, lds, st, kp, lds_entries);
         else       hipLaunchKernelGGL((path_kernel<false, false, SPILL, true>), grid, block, lds, st, kp, lds_entries);
         return;
     }
+    if (kp.two_paths) {
+        if (count) {
+            if (exact) hipLaunchKernelGGL((path_kernel_mb<true, true, SPILL, COOP>), grid, block, lds, st, kp, lds_entries);
+            else       hipLaunchKernelGGL((path_kernel_mb<false, true, SPILL, COOP>), grid, block, lds, st, kp, lds_entries);
+        } else {
+            if (exact) hipLaunchKernelGGL((path_kernel_mb<true, false, SPILL, COOP>), grid, block, lds, st, kp, lds_entries);
+            else       hipLaunchKernelGGL((path_kernel_mb<false, false, SPILL, COOP>), grid, block, lds, st, kp, lds_entries);
+        }
+        return;
+    }
     if (count) {
-        if (exact) hipLaunchKernelGGL((path_kernel<true, true, SPILL>), grid, block, lds, st, kp, lds_entries);
-        else       hipLaunchKernelGGL((path_kernel<false, true, SPILL>), grid, block, lds, st, kp, lds_entries);
+        if (exact) hipLaunchKernelGGL((path_kernel<true, true, SPILL, false, COOP>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, true, SPILL, false, COOP>), grid, block, lds, st, kp, lds_entries);
     } else {
-        if (exact) hipLaunchKernelGGL((path_kernel<true, false, SPILL>), grid, block, lds, st, kp, lds_entries);
-        else       hipLaunchKernelGGL((path_kernel<false, false, SPILL>), grid, block, lds, st, kp, lds_entries);
+        if (exact) hipLaunchKernelGGL((path_kernel<true, false, SPILL, false, COOP>), grid, block, lds, st, kp, lds_entries);
+        else       hipLaunchKernelGGL((path_kernel<false, false, SPILL, false, COOP>), grid, block, lds, st, kp, lds_entries);
     }
 }
 
 hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
     if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
     if (kp.wide && count) return hipErrorInvalidValue;
-    /* Trees of up to PT_PATH_LDS_ALL levels keep the whole stack in LDS (5 resident blocks x 30 KiB fit
-     * the CU's 160 KiB); deeper ones keep PT_PATH_LDS_STACK entries there and the rest in global memory. */
-    bool spill = kp.stack_entries > PT_PATH_LDS_ALL;
-    if (getenv("PT_FORCE_SPILL") && kp.stack_entries > PT_PATH_LDS_STACK) spill = true;
-    uint32_t lds_entries = spill ? PT_PATH_LDS_STACK : kp.stack_entries;
-    const size_t lds = block_lds_bytes(lds_entries) / PT_WAVES_PER_BLOCK * PT_PATH_WAVES_PER_BLOCK;
+    /* Resident blocks per CU are set by the registers (PT_PATH_WAVES_PER_EU waves per SIMD); each block's share of the
+     * CU's 160 KiB of LDS holds its waves' stacks and, with the quad fetch, their exchange areas.  A tree whose
+     * stack fits keeps it in LDS as a whole; a deeper one keeps the entries that fit (at least PT_PATH_LDS_MIN)
+     * there and the rest in global memory. */
+    const bool coop = !kp.wide && kp.quad_fetch;
+    const int by_registers = PT_PATH_WAVES_PER_EU * 4 / PT_PATH_WAVES_PER_BLOCK;     /* 4 SIMDs x waves per SIMD / waves per block */
+    const size_t wave_share = (160 * 1024 - 512) / (size_t)by_registers / PT_PATH_WAVES_PER_BLOCK;
+    const size_t wave_fixed = coop ? PT_XCHG_BYTES : 0;
+    uint32_t fit = wave_share > wave_fixed + 256 ? (uint32_t)((wave_share - wave_fixed) / 256) : 1u;
+    if (!coop && fit > PT_PATH_LDS_ALL) fit = PT_PATH_LDS_ALL;
+    if (fit < PT_PATH_LDS_MIN) fit = PT_PATH_LDS_MIN;
+    if (const char *e = getenv("PT_LDS_STACK_ENTRIES")) { int v = atoi(e); if (v >= (int)PT_PATH_LDS_MIN && v <= 64) fit = (uint32_t)v; }
+    bool spill = kp.stack_entries > fit;
+    if (getenv("PT_FORCE_SPILL") && kp.stack_entries > PT_PATH_LDS_MIN) {
+        spill = true;
+        if (fit >= kp.stack_entries) fit = PT_PATH_LDS_STACK < kp.stack_entries ? PT_PATH_LDS_STACK : PT_PATH_LDS_MIN;
+    }
+    uint32_t lds_entries = spill ? fit : kp.stack_entries;
+    const size_t lds = (size_t)PT_PATH_WAVES_PER_BLOCK * ((size_t)lds_entries * 256 + wave_fixed);
     /* persistent grid: as many blocks per CU as stay resident */
     int per_cu = (int)((160 * 1024 - 512) / lds);
-    const int by_registers = PT_PATH_WAVES_PER_EU * 4 / PT_PATH_WAVES_PER_BLOCK;     /* 4 SIMDs x waves per SIMD / waves per block */
     if (per_cu > by_registers) per_cu = by_registers;
     if (per_cu < 1) per_cu = 1;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu);
-    if (spill) launch_paths_variant<true>(kp, exact, count, grid, lds, lds_entries, st);
-    else       launch_paths_variant<false>(kp, exact, count, grid, lds, lds_entries, st);
+    if (coop) {
+        if (spill) launch_paths_variant<true, true>(kp, exact, count, grid, lds, lds_entries, st);
+        else       launch_paths_variant<false, true>(kp, exact, count, grid, lds, lds_entries, st);
+    } else {
+        if (spill) launch_paths_variant<true, false>(kp, exact, count, grid, lds, lds_entries, st);
+        else       launch_paths_variant<false, false>(kp, exact, count, grid, lds, lds_entries, st);
+    }
     return hipGetLastError();
 }
 

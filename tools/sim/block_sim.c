@@ -137,3 +137,97 @@ int sim_packed(const block_policy *pol, int blocks, block_result *out) {
     free(buf); free(rank);
     return 0;
 }
+
+/*
+ * sim_multibuf(): every lane of a wave owns `buffers` paths kept in memory; one of them at a time is walked
+ * through the tree in the lane's registers.  Every `service` steps a lane whose cast is complete writes the hit
+ * back (the buffer now waits for shading) and takes up one of its buffers that hold a ready ray.  The wave shades
+ * when at least `shade_min` lanes have a buffer that waits (or when `starve_min` lanes have nothing to walk and
+ * something to shade): one buffer per lane per round, so a round runs with up to 64 lanes busy.  Waves take new
+ * paths from one shared queue.  Costs in units of one traversal step.
+ */
+typedef struct {
+    int buffers, service, shade_min, starve_min, leaf_period, leaf_first, waves;
+    double cost_step, cost_shade, cost_service;
+} multibuf_policy;
+typedef struct { double time, steps, inner_lane_steps, shade_rounds, shade_lanes, services, idle_lane_steps; } multibuf_result;
+
+typedef struct { int path, cast, pos, state; } mb_t;      /* state: 0 empty, 1 ready, 2 walking, 3 waits for shading */
+
+int sim_multibuf(const multibuf_policy *pol, multibuf_result *out) {
+    memset(out, 0, sizeof(*out));
+    const int W = pol->waves, B = pol->buffers;
+    mb_t *buf = calloc((size_t)W * 64 * B, sizeof(mb_t));
+    int *active = calloc((size_t)W * 64, sizeof(int));
+    double *wave_time = calloc((size_t)W, sizeof(double));
+    long *wave_step = calloc((size_t)W, sizeof(long));
+    size_t head = 0;
+    for (int i = 0; i < W * 64; i++) active[i] = -1;
+    for (int i = 0; i < W * 64 * B; i++) { buf[i].path = -1; buf[i].state = 3; }       /* everything starts by asking for a path */
+    double measured_time = 0; int measuring = 1;
+    while (head < g_npath) {
+        int w = 0;
+        for (int k = 1; k < W; k++) if (wave_time[k] < wave_time[w]) w = k;
+        mb_t *wb = buf + (size_t)w * 64 * B;
+        int *act = active + (size_t)w * 64;
+        /* service point */
+        int swaps = 0, waiting_lanes = 0, starving = 0;
+        for (int l = 0; l < 64; l++) {
+            mb_t *bb = wb + l * B;
+            if (act[l] >= 0) {
+                mb_t *b = &bb[act[l]];
+                const cast_t *c = &g_casts[g_paths[b->path].first_cast + b->cast];
+                if (b->pos >= (int)c->n_visits) { b->state = 3; act[l] = -1; swaps++; }
+            }
+            if (act[l] < 0) for (int k = 0; k < B; k++) if (bb[k].state == 1) { bb[k].state = 2; act[l] = k; swaps++; break; }
+            int waits = 0;
+            for (int k = 0; k < B; k++) if (bb[k].state == 3) waits = 1;
+            waiting_lanes += waits;
+            if (act[l] < 0 && waits) starving++;
+        }
+        if (swaps) { out->services++; wave_time[w] += pol->cost_service; }
+        if (waiting_lanes >= pol->shade_min || starving >= pol->starve_min) {
+            int n = 0;
+            for (int l = 0; l < 64; l++) {
+                mb_t *bb = wb + l * B;
+                for (int k = 0; k < B; k++) if (bb[k].state == 3) {
+                    mb_t *b = &bb[k];
+                    n++;
+                    if (b->path >= 0 && advance_cast(b->path, &b->cast)) { b->pos = 0; b->state = 1; }
+                    else {
+                        b->state = 0; b->path = -1;
+                        for (;;) { int p = next_path(&head); if (p < 0) break; if (g_paths[p].n_casts) { b->path = p; b->cast = 0; b->pos = 0; b->state = 1; break; } }
+                    }
+                    break;
+                }
+            }
+            out->shade_rounds++; out->shade_lanes += n;
+            wave_time[w] += pol->cost_shade;
+            continue;          /* straight to another service point: the fresh rays are taken up */
+        }
+        for (int s = 0; s < pol->service; s++) {
+            const long t = wave_step[w]++;
+            const int leaf_turn = (t % pol->leaf_period) == pol->leaf_period - 1;
+            int n_inner = 0;
+            for (int l = 0; l < 64; l++) {
+                if (act[l] < 0) { out->idle_lane_steps++; continue; }
+                mb_t *b = &wb[l * B + act[l]];
+                const cast_t *c = &g_casts[g_paths[b->path].first_cast + b->cast];
+                if (b->pos >= (int)c->n_visits) continue;
+                if (g_visits[c->first_visit + b->pos]) {
+                    if (!leaf_turn) continue;
+                    b->pos++;
+                    if (!pol->leaf_first || b->pos >= (int)c->n_visits || g_visits[c->first_visit + b->pos]) continue;
+                }
+                b->pos++; n_inner++;
+            }
+            out->steps++; out->inner_lane_steps += n_inner;
+            wave_time[w] += pol->cost_step * (leaf_turn ? 1.3 : 1.0);
+        }
+    }
+    (void)measured_time; (void)measuring;
+    double sum = 0; for (int k = 0; k < W; k++) sum += wave_time[k];
+    out->time = sum / W;
+    free(buf); free(active); free(wave_time); free(wave_step);
+    return 0;
+}

@@ -63,6 +63,10 @@ def main():
     lib.sim_run(C.byref(p), C.byref(r))
     print("today (refill at 60 waiting lanes, leaves every 3rd step): %.1f inner lanes per step, %.0f steps" % (r.inner_lane_steps / r.steps, r.steps))
 
+    if os.environ.get("ONLY") == "multibuf":
+        multibuf(lib)
+        return
+
     def run_async(**kw):
         base = dict(buffers=2, latency=8, service=3, leaf_period=3, leaf_first=0, slots_per_column=0, waves=0, min_lanes=0)
         base.update(kw)
@@ -98,6 +102,30 @@ def main():
                     res = run_packed(slots_per_column=S, waves=W, min_lanes=ml, latency=lat)
                     print("slots/column %d waves %d min_lanes %2d latency %2d: %.1f lanes per wave step, %.1f wave steps per 1000 visits"
                           % (S, W, ml, lat, res.inner_lane_steps / res.wave_steps, 1000 * res.wave_steps / res.inner_lane_steps))
+
+
+class MBPolicy(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("buffers", "service", "shade_min", "starve_min", "leaf_period", "leaf_first", "waves")] + \
+               [(n, C.c_double) for n in ("cost_step", "cost_shade", "cost_service")]
+
+
+class MBResult(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("time", "steps", "inner_lane_steps", "shade_rounds", "shade_lanes", "services", "idle_lane_steps")]
+
+
+def multibuf(lib):
+    print("\nseveral paths per lane, one walked at a time, the wave shades its own waiting buffers")
+    for B in (2, 3, 4):
+        for svc in (3, 6, 9):
+            for sm in (32, 48, 56, 60):
+                for st in (8, 16, 64):
+                    pol = MBPolicy(buffers=B, service=svc, shade_min=sm, starve_min=st, leaf_period=3, leaf_first=1, waves=40,
+                                   cost_step=1.0, cost_shade=7.0, cost_service=0.3)
+                    res = MBResult()
+                    lib.sim_multibuf(C.byref(pol), C.byref(res))
+                    print("buffers %d service %d shade_min %2d starve_min %2d: time %8.0f steps %8.0f lanes/step %.1f idle %.1f rounds %6.0f (%.1f lanes) services %6.0f" % (
+                        B, svc, sm, st, res.time, res.steps, res.inner_lane_steps / res.steps, res.idle_lane_steps / res.steps,
+                        res.shade_rounds, res.shade_lanes / max(1, res.shade_rounds), res.services))
 
 
 if __name__ == "__main__":

@@ -18,12 +18,14 @@ other one is listed under `splits`.  Rank 0 prints ONE JSON line.
 Extra objects in the line:
   roofline     - the path (bounce) kernel, 98 % of the time.  It streams nothing: its working set
                  sits in L2 / Infinity Cache and what it asks of the chip is 64-lane GATHER
-                 instructions (four per BVH node visit).  The unit they all pass through is the
-                 CU's texture addresser (TA); `frac` is the share of the launch during which the
-                 TAs were busy (TA_TA_BUSY from the committed counter pass of the same workload and
-                 kernel source, profiles/path_kernel_pmc.json, scaled to the launch time measured
-                 here with HIP events).  HBM, Infinity Cache, L2 and VALU utilisation are listed
-                 next to it under `other_bounds`; the algorithmic bytes (reference layout: 36 B per
+                 instructions (four per BVH node visit).  `achieved` is the rate at which it issues
+                 them (SQ_INSTS_VMEM_RD of the committed counter pass of the same workload and kernel
+                 source, profiles/path_kernel_pmc_cfgN.json, over the launch time measured here with
+                 HIP events); `peak` is the rate at which the chip takes such gathers when nothing
+                 else is asked of it, measured by tools/ubench/gather_rate at the kernel's number of
+                 cache lines per instruction (profiles/r03_ubench_gather_ceiling.jsonl).  Address-unit
+                 busy share, HBM, Infinity Cache, L2 and VALU utilisation (busy and busy x live lanes)
+                 are listed under `other_bounds`; the algorithmic bytes (reference layout: 36 B per
                  box test, 36 B per triangle test, 48 B per sphere per cast, counted by an
                  instrumented run of the same launches) are reported as `algorithmic_over_actual`
                  against the bytes that really left the L2s.
@@ -49,6 +51,29 @@ MALL_PEAK_GBS = 8600.0       # Infinity Cache random-row gather figure of the sa
 # kernel-time efficiency of pixel sharding predicted from single-GPU runs of one rank's share
 # (tools/shard_cost.py): the persistent kernel's tail does not shrink with the image
 PREDICTED_EFFICIENCY = {"2": 0.975, "4": 0.94, "8": 0.86}
+
+
+ABSOLUTE_GATHER_GINSTR = 256 * 2.4 / 16.0        # one gather per 16 cycles and CU
+
+
+def gather_ceiling(lines_per_instruction):
+    """Peak rate of the traversal's gathers for a given number of cache lines per instruction, from the committed run of
+    tools/ubench/gather_rate ceiling (profiles/r03_ubench_gather_ceiling.jsonl): rows with one lane per line, linear
+    interpolation of the time per instruction between the two neighbouring line counts."""
+    path = os.path.join(ROOT, "profiles", "r03_ubench_gather_ceiling.jsonl")
+    if not os.path.exists(path):
+        return None
+    rows = sorted((r["lines_per_instruction"], r["ginstr_per_s"]) for r in map(json.loads, open(path)) if r["share"] == 1)
+    if not rows:
+        return None
+    x = min(max(lines_per_instruction, rows[0][0]), rows[-1][0])
+    for (l0, g0), (l1, g1) in zip(rows, rows[1:] + rows[-1:]):
+        if l0 <= x <= l1 or l1 == l0:
+            t = 0.0 if l1 == l0 else (x - l0) / (l1 - l0)
+            per_instr = (1 - t) / g0 + t / g1
+            return {"file": "profiles/r03_ubench_gather_ceiling.jsonl", "lines_per_instruction": lines_per_instruction,
+                    "between_rows": [l0, l1], "ginstr_per_s": 1.0 / per_instr}
+    return None
 
 
 def kernel_source_hash():
@@ -263,11 +288,12 @@ def main():
     # ---- roofline of the dominant kernel (rank 0) -------------------------
     if rank == 0:
         avg_ms = timing["path_ms"] / max(1, timing["batches"])
-        roof = {"kernel": "path_kernel", "bound": "vector-memory address path (TA)", "achieved": None, "peak": None,
-                "unit": "G gather instructions/s", "frac": None, "traffic": None,
+        roof = {"kernel": "path_kernel", "bound": "gather issue of the CUs' vector-memory address path", "achieved": None,
+                "peak": None, "unit": "G gather instructions/s", "frac": None, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_timed": int(timing["batches"])}
         launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
-        ppath = os.path.join(ROOT, "profiles", "path_kernel_pmc.json")
+        pfile = "profiles/path_kernel_pmc_cfg%d.json" % args.config
+        ppath = os.path.join(ROOT, pfile)
         pj = None
         if os.path.exists(ppath):
             with open(ppath) as f:
@@ -275,18 +301,33 @@ def main():
         if pj and pj.get("workload") == cfg["name"] and world == 1 and "path_kernel" in pj and timing["batches"] and not args.wide:
             d = pj["path_kernel"]
             live_s = avg_ms * 1e-3
-            roof["counter_pass"] = {"file": "profiles/path_kernel_pmc.json", "launch_ms_in_pass": d["trace_mean_ms"],
+            roof["counter_pass"] = {"file": pfile, "launch_ms_in_pass": d["trace_mean_ms"],
                                     "clock_ghz_in_pass": d["clock_ghz"],
-                                    "kernel_source_matches": pj.get("source_hash") == kernel_source_hash()}
-            if "ta_busy_cycles_per_cu" in d:
-                ta_busy_s = d["ta_busy_cycles_per_cu"] / (d["clock_ghz"] * 1e9)
+                                    "kernel_source_matches": pj.get("source_hash") == kernel_source_hash(),
+                                    "note": "counter values are those of this committed pass of the same workload, not of this run; "
+                                            "the launch time is this run's"}
+            lines = d["l1_tag_lookups"] / d["vmem_read_instructions"]
+            ceiling = gather_ceiling(lines)
+            if ceiling:
+                # achieved: vector-memory read instructions the kernel issued (SQ_INSTS_VMEM_RD of the pass) over the launch
+                # time measured here.  peak: the rate at which the chip takes such instructions when nothing else is asked
+                # of it, measured by tools/ubench/gather_rate for gathers that touch as many cache lines per instruction
+                # as the kernel's do (TCP_TOTAL_CACHE_ACCESSES / instruction of the pass).
                 roof["achieved"] = d["vmem_read_instructions"] / live_s / 1e9
-                # the rate at which the TAs would finish this launch's instruction stream if they never idled
-                roof["peak"] = d["vmem_read_instructions"] / ta_busy_s / 1e9
-                roof["frac"] = min(1.0, ta_busy_s / live_s)
+                roof["peak"] = ceiling["ginstr_per_s"]
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                roof["peak_source"] = ceiling
                 roof["gather_instructions_per_launch"] = d["vmem_read_instructions"]
-                roof["l1_tag_lookups_per_instruction"] = d["l1_tag_lookups"] / d["vmem_read_instructions"]
+                roof["cache_lines_per_gather"] = lines
+                roof["absolute_ceiling"] = {"peak": ABSOLUTE_GATHER_GINSTR, "frac": roof["achieved"] / ABSOLUTE_GATHER_GINSTR,
+                                            "note": "one 64-lane 16-byte gather per 16 cycles and CU, 256 CUs at 2.4 GHz"}
+            if "lane_stats" in d:
+                roof["inner_lanes_per_step"] = d["lane_stats"]["inner_lanes_per_step"]
             other = {}
+            scale = d["trace_mean_ms"] / avg_ms
+            if "ta_busy_frac" in d:
+                other["address_unit_busy"] = {"frac": min(1.0, d["ta_busy_frac"] * scale),
+                                              "note": "TA_TA_BUSY / (256 x cycles): a busy share, not a throughput"}
             if "hbm_side_bytes" in d:
                 roof["traffic"] = d["hbm_side_bytes"]
                 gbs = d["hbm_side_bytes"] / live_s / 1e9
@@ -298,12 +339,22 @@ def main():
                 other["l2"] = {"achieved": gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": gbs / L2_PEAK_GBS,
                                "l1_hit_rate": d["l1_hit_rate"], "l2_hit_rate": d.get("l2_hit_rate")}
             if "valu_busy_low" in d:
-                scale = d["trace_mean_ms"] / avg_ms
                 other["valu"] = {"frac_low": d["valu_busy_low"] * scale, "frac_high": d["valu_busy_high"] * scale,
                                  "lane_utilisation": d["valu_lane_utilisation"],
+                                 "useful": d["valu_busy_high"] * scale * d["valu_lane_utilisation"],
                                  "note": "issue cycles / SIMD cycles; high = SQ_ACTIVE_INST_VALU x 4 cycles (the counter's own busy "
                                          "time), low = SQ_INSTS_VALU x 2 (as if every instruction were a 2-cycle v_fma/v_mul/v_add; "
-                                         "packed f32, min/max, compares and selects take 4: tools/ubench/valu_ops)"}
+                                         "packed f32, min/max, compares and selects take 4: tools/ubench/valu_ops); useful = high x "
+                                         "the share of an instruction's 64 lanes that are live"}
+            # which memory level the scene sits in, and what binds the kernel: no level's bandwidth comes near its peak
+            scene_mb = (info["inner_nodes"] * 64 + len(tris) * 48) / 1e6 if "inner_nodes" in info else None
+            roof["binding_unit"] = {
+                "scene_resident_in": None if scene_mb is None else ("L2 (4 MiB per XCD)" if scene_mb <= 4.0 else "Infinity Cache (256 MiB)"),
+                "scene_megabytes": scene_mb,
+                "binding": "gather issue and dependent latency of the record fetches in the CUs (address unit busy %.2f, %.2f of the "
+                           "gather ceiling); bandwidth of that level: L2 %.3f, Infinity Cache / HBM %.3f of peak"
+                           % (other.get("address_unit_busy", {}).get("frac", float("nan")), roof["frac"] or float("nan"),
+                              other.get("l2", {}).get("frac", float("nan")), other.get("hbm", {}).get("frac", float("nan")))}
             roof["other_bounds"] = other
         elif world > 1:
             roof["note"] = "the counter pass describes the single-GPU launch shape; see per_rank for this run"

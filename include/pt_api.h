@@ -309,7 +309,7 @@ void pt_free(void *p);
 int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, uint32_t triangle_count, int max_depth,
                      float *triangles_out, float **nodes_out, uint32_t *node_count, float *build_ms);
 const char *pt_bvh_build_gpu_error(void);
-/* pt_bvh_build_gpu and pt_rebuild_scene keep their scratch buffers (up to 8 GiB per process) for the next build, so
+/* pt_bvh_build_gpu and pt_rebuild_scene keep their scratch buffers (up to 1 GiB per process) for the next build, so
  * that a program that rebuilds every frame does not pay hipMalloc / hipFree each time; this returns them to the driver. */
 void pt_bvh_build_gpu_release_cache(void);
 

@@ -325,9 +325,16 @@ __global__ __launch_bounds__(256) void a_index_kernel(const GNode *nodes, const 
     a_index[start + (scan[p] - scan[start])] = p;
 }
 
-/* the reference's in-place partition (main.rs:103-122) as a direct computation of every triangle's final place */
+/* the reference's in-place partition (main.rs:103-122) as a direct computation of every triangle's final place.
+ * A side-B triangle follows a chain of positions (it is thrown out by the A triangle that takes its place, lands where
+ * that one stood, and so on until it stands behind the A block).  Chains are a few links long on ordinary meshes, but
+ * an order like "one far triangle, then everything else sorted" makes one chain as long as the node: a thread gives up
+ * after CHASE_CAP links and leaves the triangle to chase_rest_kernel.  rest[0] = number of such triangles, then
+ * (position, where the chase stopped) pairs. */
+#define CHASE_CAP 32
 __global__ __launch_bounds__(256) void permute_kernel(const GNode *nodes, const uint32_t *pos_node, const uint32_t *flag, const uint32_t *scan,
-                                                      const uint32_t *a_index, const uint32_t *order, uint32_t n, uint32_t *order_next) {
+                                                      const uint32_t *a_index, const uint32_t *order, uint32_t n, uint32_t *order_next,
+                                                      uint32_t *rest) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n) return;
     const uint32_t nid = pos_node[p];
@@ -335,9 +342,49 @@ __global__ __launch_bounds__(256) void permute_kernel(const GNode *nodes, const 
     if (nid != INACTIVE && nodes[nid].permuted) {
         const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
         if (flag[p]) dest = start + (scan[p] - scan[start]);
-        else while (dest - start < n_a) dest = a_index[dest];      /* chase: thrown out by the (dest - start)-th A triangle */
+        else {
+            int links = 0;
+            while (dest - start < n_a && links < CHASE_CAP) { dest = a_index[dest]; links++; }      /* thrown out by the (dest - start)-th A triangle */
+            if (dest - start < n_a) {
+                const uint32_t k = atomicAdd(&rest[0], 1u);
+                rest[2 + 2 * (size_t)k] = p; rest[3 + 2 * (size_t)k] = dest;
+                return;
+            }
+        }
     }
     order_next[dest] = order[p];
+}
+
+/* The triangles permute_kernel gave up on (usually none: then this is one block that looks at a counter).  Pointer
+ * jumping over the chains, in place: every A slot's entry is replaced by its successor's until it points behind the A
+ * block, which halves the length of every chain per round (a reader that meets a half-updated entry still gets a
+ * position further down the same chain); then every left-over triangle is at most one link from its place. */
+__global__ __launch_bounds__(1024) void chase_rest_kernel(const GNode *nodes, const uint32_t *pos_node, uint32_t *a_index,
+                                                          const uint32_t *order, uint32_t n, uint32_t *order_next, uint32_t *rest) {
+    const uint32_t count = rest[0];
+    if (count == 0) return;
+    for (int round = 0; round < 40; round++) {
+        int changed = 0;
+        for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
+            const uint32_t nid = pos_node[x];
+            if (nid == INACTIVE || !nodes[nid].permuted) continue;
+            const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
+            if (x - start >= n_a) continue;
+            const uint32_t j = a_index[x];
+            if (j - start < n_a) { a_index[x] = a_index[j]; changed = 1; }
+        }
+        if (!__syncthreads_or(changed)) break;
+    }
+    for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) {
+        const uint32_t p = rest[2 + 2 * (size_t)k];
+        uint32_t dest = rest[3 + 2 * (size_t)k];
+        const uint32_t nid = pos_node[p];
+        const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
+        while (dest - start < n_a) dest = a_index[dest];
+        order_next[dest] = order[p];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) rest[0] = 0;
 }
 
 __global__ __launch_bounds__(64) void children_kernel(GNode *nodes, uint32_t level_begin, uint32_t level_count, const uint32_t *has_children,
@@ -463,11 +510,19 @@ __global__ __launch_bounds__(256) void write_tris_kernel(const float *tri9, cons
  * (about 15 ms against 9 ms for 784 k triangles), so freed scratch blocks are kept per device and handed out again
  * to a later build that asks for about the same size: a program that rebuilds every frame allocates once.  At most
  * CACHE_LIMIT bytes are kept; pt_bvh_build_gpu_release_cache() returns them to the driver. */
+/* The builder works on the device it is asked for and leaves the calling thread on the device it came with (a
+ * caller that shares the thread with another runtime user, e.g. torch, must not find its device changed). */
+struct DeviceRestore {
+    int prev = -1;
+    DeviceRestore() { if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; } }
+    ~DeviceRestore() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 struct CachedBlock { int device; size_t bytes; void *ptr; };
 std::mutex g_cache_mutex;
 std::vector<CachedBlock> g_cache;
 size_t g_cache_bytes = 0;
-constexpr size_t CACHE_LIMIT = (size_t)8 << 30;
+constexpr size_t CACHE_LIMIT = (size_t)1 << 30;       /* five builds of the 784 k-triangle benchmark mesh */
 
 hipError_t scratch_alloc(int device, size_t bytes, void **out, size_t *got) {
     {
@@ -541,6 +596,7 @@ void exclusive_scan(const uint32_t *in, uint32_t n, uint32_t *out, uint32_t *d_s
 extern "C" const char *pt_bvh_build_gpu_error(void) { return g_error.c_str(); }
 
 extern "C" void pt_bvh_build_gpu_release_cache(void) {
+    DeviceRestore keep;
     std::lock_guard<std::mutex> lock(g_cache_mutex);
     for (const CachedBlock &b : g_cache) {
         if (hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.ptr);
@@ -608,6 +664,9 @@ int grow_tree(const float *triangles_in, uint32_t n, int max_depth, hipStream_t 
     GB_TRY(db.alloc(d_flag, n));
     GB_TRY(db.alloc(d_scan, n));
     GB_TRY(db.alloc(d_a_index, n));
+    uint32_t *d_rest = nullptr;            /* triangles whose chase permute_kernel gave up: a counter and (position, stop) pairs */
+    GB_TRY(db.alloc(d_rest, 2 * (size_t)n + 2));
+    GB_TRY(hipMemsetAsync(d_rest, 0, 2 * sizeof(uint32_t), stream));
     GB_TRY(db.alloc(d_sums, (max_nodes + SCAN_BLOCK - 1) / SCAN_BLOCK + 1));
     GB_TRY(db.alloc(d_small, 16));          /* [0..5] root keys, [6] scan total, [7] error flag */
     GB_TRY(db.alloc(d_nodes, max_nodes));
@@ -647,7 +706,8 @@ int grow_tree(const float *triangles_in, uint32_t n, int max_depth, hipStream_t 
         hipLaunchKernelGGL(flag_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_order, d_ctr, n, d_flag);
         exclusive_scan(d_flag, n, d_scan, d_sums, d_small + 6, stream);
         hipLaunchKernelGGL(a_index_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, n, d_a_index);
-        hipLaunchKernelGGL(permute_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, d_a_index, d_order, n, d_order_next);
+        hipLaunchKernelGGL(permute_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, d_a_index, d_order, n, d_order_next, d_rest);
+        hipLaunchKernelGGL(chase_rest_kernel, dim3(1), dim3(1024), 0, stream, d_nodes, d_pos_node, d_a_index, d_order, n, d_order_next, d_rest);
         exclusive_scan(d_has, lc, d_rank_in_level, d_sums, d_small + 6, stream);
         hipLaunchKernelGGL(children_kernel, grid_for(lc, 64), dim3(64), 0, stream, d_nodes, lb, lc, d_has, d_rank_in_level, d_child_boxes, lb + lc);
         hipLaunchKernelGGL(assign_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, n, d_pos_node);
@@ -764,6 +824,7 @@ int pt_gpu_build_resident(int device_ordinal, const float *triangles, uint32_t n
     if (!triangles || n == 0 || max_depth < 0 || max_depth > 1024) return done(fail(PT_EINVAL, "bad argument"));
     int rc = check_triangles(triangles, n);
     if (rc) return done(rc);
+    DeviceRestore keep;
     if ((rc = select_device(device_ordinal))) return done(rc);
     DeviceBuffers db;
     db.device = device_ordinal;
@@ -837,6 +898,7 @@ extern "C" int pt_bvh_build_gpu(int device_ordinal, const float *triangles_in, u
         *nodes_out = out; *node_count = 1;
         return PT_OK;
     }
+    DeviceRestore keep;
     if ((rc = select_device(device_ordinal))) return rc;
     DeviceBuffers db;
     db.device = device_ordinal;

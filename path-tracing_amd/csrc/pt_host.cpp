@@ -612,6 +612,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
                     /* start this batch again with half the frames (the primary pass does not depend on
                      * the batch length except for the work counters, which such contexts do not keep) */
                     max_batch = batch / 2;
+                    /* the primary pass runs again for the shorter batch: its first timing is dropped, not counted twice */
+                    if (!c->pending.empty() && c->pending.back().kind == 0) { c->free_events.push_back(c->pending.back()); c->pending.pop_back(); }
                     continue;
                 }
                 if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");

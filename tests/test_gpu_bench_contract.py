@@ -36,21 +36,63 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["parity_spot_check"]["pixels_within_2e-3_rel"] > 0.99
 
 
+def _ceiling_rows():
+    with open(os.path.join(ROOT, "profiles", "r03_ubench_gather_ceiling.jsonl")) as f:
+        return sorted((r["lines_per_instruction"], r["ginstr_per_s"]) for r in map(json.loads, f) if r["share"] == 1)
+
+
+def _check_roofline(d, cfg_no):
+    """`frac` = achieved / peak with the two sides from different measurements: achieved = instruction count of the
+    committed counter pass over this run's launch time, peak = the gather microbenchmark's rate at the kernel's number
+    of cache lines per instruction.  Recomputed here from the files under profiles/."""
+    r = d["roofline"]
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "path_kernel_pmc_cfg%d.json" % cfg_no)))["path_kernel"]
+    assert r["counter_pass"]["file"] == "profiles/path_kernel_pmc_cfg%d.json" % cfg_no
+    assert r["peak_source"]["file"] == "profiles/r03_ubench_gather_ceiling.jsonl"
+    lines = pmc["l1_tag_lookups"] / pmc["vmem_read_instructions"]
+    assert abs(r["cache_lines_per_gather"] - lines) < 1e-9
+    rows = _ceiling_rows()
+    x = min(max(lines, rows[0][0]), rows[-1][0])
+    lo = max(k for k in range(len(rows)) if rows[k][0] <= x)
+    hi = min(lo + 1, len(rows) - 1)
+    t = 0.0 if hi == lo else (x - rows[lo][0]) / (rows[hi][0] - rows[lo][0])
+    peak = 1.0 / ((1 - t) / rows[lo][1] + t / rows[hi][1])
+    assert abs(r["peak"] - peak) < 1e-6 * peak
+    achieved = pmc["vmem_read_instructions"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+    assert abs(r["achieved"] - achieved) < 1e-6 * achieved
+    assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["peak"] <= r["absolute_ceiling"]["peak"] * 1.001          # the tighter of the two ceilings is the one quoted
+    ob = r["other_bounds"]
+    assert 0 < ob["hbm"]["frac"] < 0.2 and 0 < ob["l2"]["frac"] < 0.5 and 0 < ob["valu"]["frac_low"] < ob["valu"]["frac_high"] <= 1
+    assert abs(ob["valu"]["useful"] - ob["valu"]["frac_high"] * ob["valu"]["lane_utilisation"]) < 1e-9
+    assert 0 < ob["address_unit_busy"]["frac"] <= 1
+    assert r["binding_unit"]["scene_resident_in"] in ("L2 (4 MiB per XCD)", "Infinity Cache (256 MiB)")
+
+
 def test_headline_roofline_is_a_physical_fraction():
-    """The default (headline) configuration: the roofline names the binding unit and its busy share is in (0, 1];
+    """The default (headline) configuration: `peak` comes from the microbenchmark file, `frac` is in (0, 1);
     HBM-side traffic is far below the algorithmic bytes (the tree is cache resident)."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
     assert d["metric"] == "Msamples/s at 1080p dragon_800k, 8 bounces" and d["config"]["workload"].startswith("dragon_800k_synth")
+    _check_roofline(d, 4)
     r = d["roofline"]
-    assert 0 < r["frac"] <= 1 and r["achieved"] > 0 and abs(r["frac"] - min(1.0, r["achieved"] / r["peak"])) < 1e-9
     assert r["traffic"] > 0 and r["algorithmic_over_actual"] > 10
-    ob = r["other_bounds"]
-    assert 0 < ob["hbm"]["frac"] < 0.2 and 0 < ob["l2"]["frac"] < 0.5 and 0 < ob["valu"]["frac_low"] < ob["valu"]["frac_high"] <= 1
+    assert r["binding_unit"]["scene_resident_in"] == "Infinity Cache (256 MiB)"
     # executed casts, not the reference's count: below 2 casts per sample on this scene
     assert r["executed_ray_casts_per_step"] < r["reference_ray_casts_per_step"]
+
+
+@pytest.mark.parametrize("cfg_no,level", [(2, "L2 (4 MiB per XCD)"), (3, "Infinity Cache (256 MiB)"), (5, "L2 (4 MiB per XCD)")])
+def test_other_configurations_have_a_roofline_from_their_own_counter_pass(cfg_no, level):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", str(cfg_no), "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-count"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.strip()][-1])
+    _check_roofline(d, cfg_no)
+    assert d["roofline"]["binding_unit"]["scene_resident_in"] == level
 
 
 @pytest.mark.parametrize("shard", ["pixels", "frames"])

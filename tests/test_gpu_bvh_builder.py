@@ -154,3 +154,25 @@ def test_scratch_cache_is_reused_and_can_be_released(pkg, scenes):
     assert np.array_equal(bits(a[1]), bits(b[1])) and np.array_equal(bits(a[0]), bits(b[0]))
     L.pt_bvh_build_gpu_release_cache()
     assert free0 - torch.cuda.mem_get_info(0)[0] < (64 << 20)
+
+
+@pytest.mark.parametrize("n", [5000, 300000])
+def test_gpu_builder_adversarial_order_has_no_time_cliff(pkg, n):
+    """One far triangle first, then all the others in descending order along an axis: in every node whose split sends
+    the first triangle to side B and the rest to side A, the in-place partition (main.rs:103-122) moves that triangle
+    through a chain of positions as long as the node.  The builder resolves such chains by pointer jumping, so the
+    result is still the host builder's and the time stays in milliseconds (a thread that walked the chain link by
+    link would take of the order of a second for 300 000 links)."""
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(0.0, 1000.0, n).astype(F))[::-1]           # descending centres
+    c = np.stack([x, rng.uniform(0, 1, n).astype(F), rng.uniform(0, 1, n).astype(F)], axis=1)
+    c[0, 0] = F(5000.0)                                                 # the far one, first
+    d = rng.uniform(-0.2, 0.2, (n, 3, 3)).astype(F)
+    tris = (c[:, None, :] + d).reshape(n, 9).astype(F)
+    t1, n1 = pkg.bvh_build(tris, 24)
+    pkg.bvh_build_gpu(tris[:1000], 8)
+    t2, n2, ms = pkg.bvh_build_gpu(tris, 24, return_ms=True)
+    assert np.array_equal(bits(n1), bits(n2))
+    assert np.array_equal(bits(t1), bits(t2))
+    print("adversarial order, %d triangles: %.2f ms on the device" % (n, ms))
+    assert ms < 150.0

@@ -97,6 +97,9 @@ def main(prof, out):
             d["hbm_side_read_bytes"] = pk["FETCH_SIZE"] * 1024.0 * read_factor
             d["hbm_side_write_bytes"] = pk["WRITE_SIZE"] * 1024.0
             d["hbm_side_bytes"] = d["hbm_side_read_bytes"] + d["hbm_side_write_bytes"]
+        ks = os.path.join(prof, "kstats.json")
+        if os.path.exists(ks):            # lane diagnostics of an instrumented run of the same workload (tools/kernel_stats.py)
+            d["lane_stats"] = json.load(open(ks))
         res["path_kernel"] = d
     with open(out, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)

@@ -22,6 +22,8 @@ run pmc_tcc --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum TCP_TOTAL_CA
 run pmc_ta --pmc TA_TA_BUSY_sum TA_BUFFER_TOTAL_CYCLES_sum TD_TD_BUSY_sum TD_TC_STALL_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum || exit 1
 run pmc_fetch --pmc FETCH_SIZE || exit 1
 run pmc_write --pmc WRITE_SIZE || exit 1
+CFG=4; prev=""; for a in "$@"; do [ "$prev" = "--config" ] && CFG=$a; prev=$a; done
+timeout -k 10 200 python3 "$R/tools/kernel_stats.py" $CFG --json "$OUT/kstats.json" > "$OUT/kstats.txt" 2>&1 || { tail -5 "$OUT/kstats.txt"; exit 1; }
 python3 "$R/tools/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
 python3 "$R/tools/pmc_json.py" "$OUT" "$OUT/path_kernel_pmc.json" > "$OUT/pmc_json.log" 2>&1 || { cat "$OUT/pmc_json.log"; exit 1; }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <string>
 #include <cstdint>
 
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
@@ -75,7 +76,39 @@ static double run(const void *d, uint32_t n, int blocks_per_cu, int iters, unsig
     return ms;
 }
 
+// "ceiling": the rate at which the chip takes the traversal's gathers (four per visit, L2-resident table, 6 waves per
+// SIMD) as a function of the live lanes per wave and of how many of them share a record, one JSON object per line.
+// lines_per_instruction = distinct records a wave's instruction touches (what the vector L1 counts as tag lookups).
+static int ceiling(void) {
+    uint32_t *out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
+    const uint32_t n = 8192;
+    std::vector<uint32_t> t;
+    fill(t, n);
+    void *d; CHECK(hipMalloc(&d, (size_t)n * 64));
+    CHECK(hipMemcpy(d, t.data(), (size_t)n * 64, hipMemcpyHostToDevice));
+    const int w = 6, iters = 6000;
+    for (int lanes : {16, 24, 32, 36, 40, 44, 48, 56, 64})
+        for (uint32_t share : {1u, 2u, 4u, 8u}) {
+            unsigned long long mask = 0;
+            for (int l = 0; l < lanes; l++) mask |= 1ull << ((l * 64) / lanes);
+            int lines = 0;                       /* distinct chains among the active lanes of a wave */
+            for (uint32_t g = 0; g < 64; g += share) {
+                bool any = false;
+                for (uint32_t l = g; l < g + share && l < 64; l++) any = any || ((mask >> l) & 1ull);
+                lines += any;
+            }
+            double best = 1e30;
+            for (int rep = 0; rep < 3; rep++) { double ms = run<4>(d, n, w, iters, mask, out, share); if (ms < best) best = ms; }
+            const double instr = 256.0 * 4 * w * (double)iters * 4;      /* CUs x SIMDs x waves x visits x gathers per visit */
+            printf("{\"lanes\": %d, \"share\": %u, \"lines_per_instruction\": %d, \"ms\": %.4f, \"gather_instructions\": %.0f, "
+                   "\"ginstr_per_s\": %.3f, \"cycles_per_instruction_per_cu_at_2400mhz\": %.2f}\n",
+                   lanes, share, lines, best, instr, instr / (best * 1e6), best * 1e3 * 2400.0 * 256.0 / instr);
+        }
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && std::string(argv[1]) == "ceiling") return ceiling();
     if (argc > 1) {      /* counter pass: few launches, told apart by their order */
         uint32_t *out; CHECK(hipMalloc(&out, 256 * 8 * 256 * 4));
         const uint32_t n = 8192;

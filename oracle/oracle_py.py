@@ -68,8 +68,13 @@ class Oracle:
     log/cos/pow are the portable polynomial versions (bit-exact with the HIP
     kernels' exact-math mode)."""
 
-    def __init__(self, shared_math=False):
+    def __init__(self, shared_math=False, variant=None):
+        """variant: one of the oracle/variants builds (shared math with ONE built-in evaluated another way a WGSL
+        implementation may choose: normalize_div, dot_fma, minmax_nan, camera_f32, contract); None = the pinned choices."""
         name = "libpt_oracle_shared.so" if shared_math else "libpt_oracle.so"
+        if variant:
+            assert shared_math, "the variants are builds of the shared-math oracle"
+            name = os.path.join("variants", "libpt_oracle_%s.so" % variant)
         path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()

@@ -14,7 +14,11 @@
 #endif
 
 #ifdef ORC_SHARED_MATH
+/* log / cos / pow keep their own arithmetic in every build (the "contract" variant fuses the shader's expressions only) */
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
 #include "../path-tracing_amd/csrc/pt_portable_math.h"
+#pragma GCC pop_options
 #define ORC_LOG(x) pm_logf(x)
 #define ORC_COS(x) pm_cosf(x)
 #define ORC_POW(x, y) pm_powf((x), (y))
@@ -41,16 +45,44 @@ static inline orc_v3 vadd(orc_v3 a, orc_v3 b) { return v3(a.x + b.x, a.y + b.y, 
 static inline orc_v3 vsub(orc_v3 a, orc_v3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline orc_v3 vmul(orc_v3 a, orc_v3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 static inline orc_v3 vscale(orc_v3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+/* Built-ins whose rounding WGSL leaves to the implementation are pinned as pt_oracle.h says.  The ORC_VAR_* builds
+ * make one other choice each that a WGSL implementation may legally make; they exist to measure how much of the
+ * pinned results hangs on the choice (tests/test_builtin_variants.py), and nothing else uses them. */
+#ifdef ORC_VAR_DOT_FMA        /* dot() as a chain of fused multiply-adds */
+static inline float vdot(orc_v3 a, orc_v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+#else
 static inline float vdot(orc_v3 a, orc_v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+#endif
 static inline orc_v3 vcross(orc_v3 a, orc_v3 b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
+#ifdef ORC_VAR_NORMALIZE_DIV  /* normalize(v) = v / length(v), one division per component */
+static inline orc_v3 vnormalize(orc_v3 a) {
+    float len = sqrtf(vdot(a, a));
+    return v3(a.x / len, a.y / len, a.z / len);
+}
+#else
 static inline orc_v3 vnormalize(orc_v3 a) {
     float inv = 1.0f / sqrtf(vdot(a, a));
     return vscale(a, inv);
 }
+#endif
+#ifdef ORC_VAR_MINMAX_NAN     /* min / max (and the clamp of smoothstep) hand a NaN operand on */
+static inline float minnum(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+static inline float maxnum(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+#else
 static inline float minnum(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a < b ? a : b)); }
 static inline float maxnum(float a, float b) { return (b != b) ? a : ((a != a) ? b : (a > b ? a : b)); }
+#endif
+#ifdef ORC_VAR_CAMERA_F32     /* the camera's sin / cos / tan in binary32 (libm) instead of double, rounded once */
+#define ORC_CAM_SIN(x) sinf(x)
+#define ORC_CAM_COS(x) cosf(x)
+#define ORC_CAM_TAN(x) tanf(x)
+#else
+#define ORC_CAM_SIN(x) ((float)sin((double)(x)))
+#define ORC_CAM_COS(x) ((float)cos((double)(x)))
+#define ORC_CAM_TAN(x) ((float)tan((double)(x)))
+#endif
 static inline orc_v3 from3(const float *p) { return v3(p[0], p[1], p[2]); }
 
 /* shader.wgsl:385-388 */
@@ -125,9 +157,9 @@ static orc_v3 rotate_vector(orc_v3 ray, orc_v3 angles) {
     float a = angles.x * ORC_PI / 180.0f;
     float b = angles.y * ORC_PI / 180.0f;
     float c = angles.z * ORC_PI / 180.0f;
-    float cos_a = (float)cos((double)a), sin_a = (float)sin((double)a);
-    float cos_b = (float)cos((double)b), sin_b = (float)sin((double)b);
-    float cos_c = (float)cos((double)c), sin_c = (float)sin((double)c);
+    float cos_a = ORC_CAM_COS(a), sin_a = ORC_CAM_SIN(a);
+    float cos_b = ORC_CAM_COS(b), sin_b = ORC_CAM_SIN(b);
+    float cos_c = ORC_CAM_COS(c), sin_c = ORC_CAM_SIN(c);
     float x_rot = x * cos_c * cos_b + y * (cos_c * sin_b * sin_a - sin_c * cos_a) + z * (cos_c * sin_b * cos_a + sin_c * sin_a);
     float y_rot = x * sin_c * cos_b + y * (sin_c * sin_b * sin_a + cos_c * cos_a) + z * (sin_c * sin_b * cos_a - cos_c * sin_a);
     float z_rot = -x * sin_b + y * cos_b * sin_a + z * cos_b * cos_a;
@@ -145,7 +177,7 @@ void orc_screen_size(const orc_params *p, float *screen_width, float *screen_hei
      * abstract floats: evaluated in f64, rounded to f32 once (shader.wgsl:36) */
     float fov = (float)((double)p->fov_degrees * 3.14159 / 180.0);
     float aspect = (float)p->width / (float)p->height;
-    float sw = (float)tan((double)(fov * 0.5f)) * 2.0f;
+    float sw = ORC_CAM_TAN(fov * 0.5f) * 2.0f;
     *screen_width = sw;
     *screen_height = sw / aspect;
 }

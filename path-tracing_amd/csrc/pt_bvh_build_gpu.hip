@@ -329,9 +329,9 @@ __global__ __launch_bounds__(256) void a_index_kernel(const GNode *nodes, const 
  * A side-B triangle follows a chain of positions (it is thrown out by the A triangle that takes its place, lands where
  * that one stood, and so on until it stands behind the A block).  Chains are a few links long on ordinary meshes, but
  * an order like "one far triangle, then everything else sorted" makes one chain as long as the node: a thread gives up
- * after CHASE_CAP links and leaves the triangle to chase_rest_kernel.  rest[0] = number of such triangles, then
+ * after CHASE_CAP links and leaves the triangle to jump_kernel + chase_rest_kernel.  rest[0] = number of such triangles, then
  * (position, where the chase stopped) pairs. */
-#define CHASE_CAP 32
+#define CHASE_CAP 1024
 __global__ __launch_bounds__(256) void permute_kernel(const GNode *nodes, const uint32_t *pos_node, const uint32_t *flag, const uint32_t *scan,
                                                       const uint32_t *a_index, const uint32_t *order, uint32_t n, uint32_t *order_next,
                                                       uint32_t *rest) {
@@ -355,36 +355,38 @@ __global__ __launch_bounds__(256) void permute_kernel(const GNode *nodes, const 
     order_next[dest] = order[p];
 }
 
-/* The triangles permute_kernel gave up on (usually none: then this is one block that looks at a counter).  Pointer
- * jumping over the chains, in place: every A slot's entry is replaced by its successor's until it points behind the A
- * block, which halves the length of every chain per round (a reader that meets a half-updated entry still gets a
- * position further down the same chain); then every left-over triangle is at most one link from its place. */
-__global__ __launch_bounds__(1024) void chase_rest_kernel(const GNode *nodes, const uint32_t *pos_node, uint32_t *a_index,
-                                                          const uint32_t *order, uint32_t n, uint32_t *order_next, uint32_t *rest) {
-    const uint32_t count = rest[0];
-    if (count == 0) return;
-    for (int round = 0; round < 40; round++) {
-        int changed = 0;
-        for (uint32_t x = threadIdx.x; x < n; x += blockDim.x) {
-            const uint32_t nid = pos_node[x];
-            if (nid == INACTIVE || !nodes[nid].permuted) continue;
-            const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
-            if (x - start >= n_a) continue;
-            const uint32_t j = a_index[x];
-            if (j - start < n_a) { a_index[x] = a_index[j]; changed = 1; }
-        }
-        if (!__syncthreads_or(changed)) break;
+/* The triangles permute_kernel gave up on (usually none: then both kernels below look at a counter and return).
+ * Pointer jumping over the chains, in place and without rounds: every A slot's entry is replaced by its successor's
+ * until it points behind the A block.  A thread that meets a half-updated entry still gets a position further down
+ * the same chain, so no synchronisation is needed, and with all threads at it a chain of n links collapses in about
+ * log2(n) replacements per slot.  Afterwards every left-over triangle is a link or two from its place. */
+__global__ __launch_bounds__(256) void jump_kernel(const GNode *nodes, const uint32_t *pos_node, uint32_t *a_index, uint32_t n,
+                                                   const uint32_t *rest) {
+    if (rest[0] == 0) return;
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= n) return;
+    const uint32_t nid = pos_node[x];
+    if (nid == INACTIVE || !nodes[nid].permuted) return;
+    const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
+    if (x - start >= n_a) return;
+    volatile uint32_t *a = a_index;
+    for (int it = 0; it < 64; it++) {
+        const uint32_t j = a[x];
+        if (j - start >= n_a) break;
+        a[x] = a[j];
     }
-    for (uint32_t k = threadIdx.x; k < count; k += blockDim.x) {
-        const uint32_t p = rest[2 + 2 * (size_t)k];
-        uint32_t dest = rest[3 + 2 * (size_t)k];
-        const uint32_t nid = pos_node[p];
-        const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
-        while (dest - start < n_a) dest = a_index[dest];
-        order_next[dest] = order[p];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) rest[0] = 0;
+}
+
+__global__ __launch_bounds__(256) void chase_rest_kernel(const GNode *nodes, const uint32_t *pos_node, const uint32_t *a_index,
+                                                         const uint32_t *order, uint32_t *order_next, const uint32_t *rest) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= rest[0]) return;
+    const uint32_t p = rest[2 + 2 * (size_t)k];
+    uint32_t dest = rest[3 + 2 * (size_t)k];
+    const uint32_t nid = pos_node[p];
+    const uint32_t start = nodes[nid].start, n_a = nodes[nid].n_a;
+    while (dest - start < n_a) dest = a_index[dest];
+    order_next[dest] = order[p];
 }
 
 __global__ __launch_bounds__(64) void children_kernel(GNode *nodes, uint32_t level_begin, uint32_t level_count, const uint32_t *has_children,
@@ -707,7 +709,9 @@ int grow_tree(const float *triangles_in, uint32_t n, int max_depth, hipStream_t 
         exclusive_scan(d_flag, n, d_scan, d_sums, d_small + 6, stream);
         hipLaunchKernelGGL(a_index_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, n, d_a_index);
         hipLaunchKernelGGL(permute_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_flag, d_scan, d_a_index, d_order, n, d_order_next, d_rest);
-        hipLaunchKernelGGL(chase_rest_kernel, dim3(1), dim3(1024), 0, stream, d_nodes, d_pos_node, d_a_index, d_order, n, d_order_next, d_rest);
+        hipLaunchKernelGGL(jump_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_a_index, n, d_rest);
+        hipLaunchKernelGGL(chase_rest_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, d_pos_node, d_a_index, d_order, d_order_next, d_rest);
+        GB_TRY(hipMemsetAsync(d_rest, 0, sizeof(uint32_t), stream));
         exclusive_scan(d_has, lc, d_rank_in_level, d_sums, d_small + 6, stream);
         hipLaunchKernelGGL(children_kernel, grid_for(lc, 64), dim3(64), 0, stream, d_nodes, lb, lc, d_has, d_rank_in_level, d_child_boxes, lb + lc);
         hipLaunchKernelGGL(assign_kernel, grid_for(n, 256), dim3(256), 0, stream, d_nodes, n, d_pos_node);

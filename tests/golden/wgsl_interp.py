@@ -625,14 +625,42 @@ def _f(v):
 
 
 class Builtins:
-    def __init__(self, math_provider):
+    """The built-in functions.  WGSL leaves the rounding of several of them to the implementation; the default choices
+    are the ones the oracle and the kernels pin.  `choices` swaps single ones for another legal evaluation, to measure
+    what hangs on them: normalize="div" (v / length(v)), dot="fma" (a chain of fused multiply-adds), minmax="nan"
+    (a NaN operand is handed on), camera="f32" (sin / cos / tan of the camera angles in binary32)."""
+
+    def __init__(self, math_provider, choices=None):
         self.mp = math_provider
+        self.choices = dict(choices or {})
+        unknown = set(self.choices) - {"normalize", "dot", "minmax", "camera"}
+        if unknown:
+            raise ValueError("unknown built-in choice: %s" % sorted(unknown))
+        self._fmaf = None
+
+    def fma(self, a, b, c):
+        if self._fmaf is None:
+            import ctypes
+            import ctypes.util
+            m = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+            m.fmaf.restype = ctypes.c_float
+            m.fmaf.argtypes = [ctypes.c_float] * 3
+            m.tanf.restype = ctypes.c_float
+            m.tanf.argtypes = [ctypes.c_float]
+            self._libm = m
+            self._fmaf = m.fmaf
+        return F32(self._fmaf(float(a), float(b), float(c)))
 
     def dot(self, a, b):
         acc = a.c[0] * b.c[0]
         for x, y in zip(a.c[1:], b.c[1:]):
-            acc = acc + x * y
+            acc = self.fma(x, y, acc) if self.choices.get("dot") == "fma" else acc + x * y
         return acc
+
+    def minmax(self, name, x, y):
+        if self.choices.get("minmax") == "nan" and (x != x or y != y):
+            return F32(np.nan)
+        return F32((np.fmin if name == "min" else np.fmax)(x, y))        # IEEE minNum / maxNum
 
     def call(self, name, args, where):
         with np.errstate(all="ignore"):
@@ -646,6 +674,9 @@ class Builtins:
             return Vec((a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]))
         if name == "normalize":
             v = _f(args[0])
+            if self.choices.get("normalize") == "div":
+                length = F32(np.sqrt(self.dot(v, v)))
+                return Vec(x / length for x in v.c)
             inv = F32(1.0) / np.sqrt(self.dot(v, v))
             return Vec(x * inv for x in v.c)
         if name == "reflect":
@@ -654,14 +685,13 @@ class Builtins:
             return Vec(x - y * k for x, y in zip(i.c, n.c))
         if name in ("min", "max"):
             a, b = _f(args[0]), _f(args[1])
-            fn = np.fmin if name == "min" else np.fmax        # IEEE minNum / maxNum
             if isinstance(a, Vec):
-                return Vec(F32(fn(x, y)) for x, y in zip(a.c, b.c))
-            return F32(fn(a, b))
+                return Vec(self.minmax(name, x, y) for x, y in zip(a.c, b.c))
+            return self.minmax(name, a, b)
         if name == "smoothstep":
             e0, e1, x = (_f(v) for v in args)
             t = (x - e0) / (e1 - e0)
-            t = F32(np.fmin(np.fmax(t, F32(0.0)), F32(1.0)))
+            t = self.minmax("min", self.minmax("max", t, F32(0.0)), F32(1.0))
             return t * t * (F32(3.0) - F32(2.0) * t)
         if name == "sqrt":
             return F32(np.sqrt(_f(args[0])))
@@ -673,6 +703,11 @@ class Builtins:
         if name in ("cos", "sin", "tan"):
             x = _f(args[0])
             if where in CAMERA_FUNCTIONS:            # camera angles: evaluated in double, rounded once
+                if self.choices.get("camera") == "f32":
+                    if name == "tan":
+                        self.fma(F32(0.0), F32(0.0), F32(0.0))        # loads libm
+                        return F32(self._libm.tanf(float(x)))
+                    return getattr(LibmMath(), name)(x)
                 return F32(getattr(math, name)(float(x)))
             if name == "tan":
                 raise NotImplementedError("tan outside the camera set-up")

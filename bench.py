@@ -120,7 +120,13 @@ def launch_ranks(n):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd).returncode
+    # the line of rank 0 goes to stdout; whatever else the ranks' libraries write there (gloo announces its
+    # connections on stdout) goes to stderr, so that stdout holds the one JSON line
+    with subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True) as child:
+        for line in child.stdout:
+            (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+            sys.stdout.flush()
+        return child.wait()
 
 
 def main():

@@ -121,8 +121,8 @@ def test_plain_bench_command_starts_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--steps", "2",
                           "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines          # nothing but the JSON line on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank"]) == 2
     assert sorted(p["rank"] for p in d["per_rank"]) == [0, 1]

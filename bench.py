@@ -298,6 +298,11 @@ def main():
                 "peak": None, "unit": "G gather instructions/s", "frac": None, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_timed": int(timing["batches"])}
         launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
+        # Consecutive batches run on two streams: the next launch starts while this one drains, so the launches' own
+        # durations (avg_launch_ms, which the roofline is quoted on, as a profiler would see them) add up to more than
+        # the wall time.
+        roof["wall_ms_per_launch"] = elapsed / args.steps * 1e3 / launches_per_step if launches_per_step else None
+        roof["launches_overlap"] = bool(launches_per_step and avg_ms > roof["wall_ms_per_launch"])
         pfile = "profiles/path_kernel_pmc_cfg%d.json" % args.config
         ppath = os.path.join(ROOT, pfile)
         pj = None

@@ -63,11 +63,50 @@ struct EventPair { hipEvent_t start, stop; int kind; };
 
 }  // namespace
 
+/*
+ * What one batch of frames in flight owns: a stream, the hit list and per-pixel tables of the primary pass, the
+ * control words, the sample buffer, the overflow area of the traversal stacks.  A context has two.  The path kernel
+ * is a persistent grid whose last waves wait for single long paths while most of the GPU idles; the kernels of the
+ * next batch, enqueued on the OTHER slot's stream, become resident as those blocks retire.  Only the resolve kernels
+ * (which fold the frames into the accumulation buffer, in frame order) are chained across the two streams.
+ * Slot 0 is made by pt_create; slot 1 by the first batch that is pipelined.
+ */
+struct BatchSlot {
+    hipStream_t stream = nullptr;
+    PTHitRecord *d_hits = nullptr;
+    PTControl *d_ctrl = nullptr;
+    uint32_t *d_pixel_hit = nullptr;
+    float4 *d_pixel_const = nullptr;
+    float4 *d_samples = nullptr;
+    size_t sample_slots = 0;           /* float4 slots d_samples holds (allocated by the render calls, grow-only) */
+    uint32_t *d_spill = nullptr;
+    size_t spill_words = 0;
+    uint32_t *h_hit_count = nullptr;   /* pinned host word the hit count of the primary pass is copied to */
+    hipEvent_t accum_done = nullptr;   /* recorded behind this slot's last operation on the accumulation buffer */
+    /* The primary pass depends on camera, scene, parameters and pixel shard only: its results are kept and reused by
+     * later batches (of this and later calls) until one of those changes (pt_ctx::view_epoch). */
+    unsigned long long primary_epoch = 0;      /* view_epoch the tables were made for; 0 = none */
+    bool queue_clean = false;                  /* the queue heads in d_ctrl are zero (the resolve kernel leaves them so) */
+    bool hit_count_pending = false;            /* the copy to h_hit_count is enqueued, hit_count not yet read */
+    uint32_t hit_count = 0;
+    bool ready = false;
+};
+
 struct pt_ctx {
     unsigned long long serial = 0;     /* distinguishes contexts for the static-scratch guard (addresses are reused) */
     int device = 0;
     int num_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      /* = slot[0].stream: everything that is not a batch of frames runs here */
+    BatchSlot slot[2];
+    int last_slot = 0;                 /* slot of the batch enqueued last */
+    int accum_last = -1;               /* slot whose stream touched the accumulation buffer last (-1: none yet) */
+    unsigned long long view_epoch = 1; /* bumped by whatever changes the primary pass's results */
+    bool pipeline = true;              /* PT_PIPELINE=0: every batch on slot 0 */
+    bool adapt_grid = true;            /* PT_ADAPT_GRID=0: the path kernel always gets its full grid */
+    size_t pipeline_bytes = (size_t)16 << 30;  /* largest sample buffer a pipelined batch may need (PT_PIPELINE_MB) */
+    size_t spill_words = 0;            /* size the scene asks of BatchSlot::d_spill */
+    unsigned long long known_hits_epoch = 0;   /* view_epoch for which known_hits is the primary pass's hit count */
+    uint32_t known_hits = 0;
     pt_params params{};
     float cam_pos[3] = {200.0f, 0.0f, 200.0f};      /* src/main.rs:382 */
     float cam_rot[3] = {0.0f, 90.0f, 0.0f};         /* src/main.rs:383 */
@@ -81,20 +120,12 @@ struct pt_ctx {
     int wide_stack_entries = 0;
     float4 *d_accum_own = nullptr;
     float4 *d_accum = nullptr;
-    PTHitRecord *d_hits = nullptr;
-    PTControl *d_ctrl = nullptr;
-    float4 *d_samples = nullptr;
-    uint32_t *d_spill = nullptr;
-    uint32_t *d_pixel_hit = nullptr;
-    float4 *d_pixel_const = nullptr;
-    size_t sample_slots = 0;           /* float4 slots d_samples holds (allocated by the render calls, grow-only) */
-    size_t sample_budget = 0;          /* most bytes d_samples may take */
+    size_t sample_budget = 0;          /* most bytes one slot's sample buffer may take */
     /* Batches whose worst case (every pixel a hit pixel) stays below this allocate for the worst case and
      * stay asynchronous; larger ones wait for the primary pass and size the buffer by the hit count.
      * 1 GiB; PT_SMALL_SAMPLE_MB overrides (0: always by hit count). */
     size_t small_sample_bytes = (size_t)1 << 30;
     uint32_t batch_cap = 1;            /* most frames one batch may hold (32-bit slot numbers, at most 64) */
-    uint32_t *h_hit_count = nullptr;   /* pinned host word the hit count of a batch is copied to */
     unsigned long long *d_counters = nullptr;
     int32_t *d_ids = nullptr;
     float *d_dist = nullptr;
@@ -390,7 +421,7 @@ int validate_params(const pt_params *p, std::string &why) {
     return PT_OK;
 }
 
-void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_stride, uint32_t batch_frames,
+void fill_kernel_params(const pt_ctx *c, const BatchSlot &bs, uint32_t frame_first, uint32_t frame_stride, uint32_t batch_frames,
                         uint32_t accum_mode, PTKernelParams &k) {
     memset(&k, 0, sizeof(k));
     const pt_params &p = c->params;
@@ -453,9 +484,9 @@ void fill_kernel_params(const pt_ctx *c, uint32_t frame_first, uint32_t frame_st
     k.xcd_queues = getenv("PT_NO_XCD_QUEUES") ? 0u : 1u;
     k.inner = c->d_inner; k.inner_bytes = (c->inner_count ? c->inner_count : 1u) * (uint32_t)sizeof(PTInnerRecord);
     k.tris_bytes = (c->tri_count ? c->tri_count : 1u) * (uint32_t)sizeof(PTTriRecord); k.tris = c->d_tris; k.spheres = c->d_spheres; k.big_leaf_count = c->d_big;
-    k.accum = c->d_accum; k.hits = c->d_hits; k.ctrl = c->d_ctrl; k.samples = c->d_samples;
-    k.pixel_hit = c->d_pixel_hit; k.pixel_const = c->d_pixel_const;
-    k.spill = c->d_spill; k.spill_stride = pt_lane_stride(c->num_cus);
+    k.accum = c->d_accum; k.hits = bs.d_hits; k.ctrl = bs.d_ctrl; k.samples = bs.d_samples;
+    k.pixel_hit = bs.d_pixel_hit; k.pixel_const = bs.d_pixel_const;
+    k.spill = bs.d_spill; k.spill_stride = pt_lane_stride(c->num_cus);
     k.out_ids = c->d_ids; k.out_dist = c->d_dist; k.counters = c->d_counters;
 }
 
@@ -480,12 +511,70 @@ int drain_events(pt_ctx *c) {
 }
 
 struct Timed {
-    pt_ctx *c; EventPair ep; bool ok;
-    Timed(pt_ctx *ctx, int kind) : c(ctx), ok(false) {
-        if (get_event_pair(c, ep) == PT_OK) { ep.kind = kind; ok = hipEventRecord(ep.start, c->stream) == hipSuccess; }
+    pt_ctx *c; hipStream_t st; EventPair ep; bool ok;
+    Timed(pt_ctx *ctx, hipStream_t stream, int kind) : c(ctx), st(stream), ok(false) {
+        if (get_event_pair(c, ep) == PT_OK) { ep.kind = kind; ok = hipEventRecord(ep.start, st) == hipSuccess; }
     }
-    void done() { if (ok) { (void)hipEventRecord(ep.stop, c->stream); c->pending.push_back(ep); } }
+    void done() { if (ok) { (void)hipEventRecord(ep.stop, st); c->pending.push_back(ep); } }
 };
+
+/* waits for everything the context has enqueued, on both slots' streams */
+hipError_t sync_all(pt_ctx *c) {
+    hipError_t e = hipSuccess;
+    for (int s = 0; s < 2; s++)
+        if (c->slot[s].stream) { hipError_t es = hipStreamSynchronize(c->slot[s].stream); if (e == hipSuccess) e = es; }
+    return e;
+}
+
+/* The accumulation buffer is written in a fixed order (a running mean is folded frame by frame).  Whatever touches
+ * it on slot s's stream first waits for the last such operation of the other stream, and leaves its own mark. */
+hipError_t accum_wait(pt_ctx *c, int s) {
+    if (c->accum_last < 0 || c->accum_last == s) return hipSuccess;
+    return hipStreamWaitEvent(c->slot[s].stream, c->slot[c->accum_last].accum_done, 0);
+}
+hipError_t accum_mark(pt_ctx *c, int s) {
+    c->accum_last = s;
+    return hipEventRecord(c->slot[s].accum_done, c->slot[s].stream);
+}
+
+/* stream, event, pinned word and the per-pixel buffers of a slot (not its sample buffer and stack overflow area:
+ * the render calls size those) */
+hipError_t slot_prepare(pt_ctx *c, int s) {
+    BatchSlot &b = c->slot[s];
+    if (b.ready) return hipSuccess;
+    const size_t npix = (size_t)c->params.width * c->params.height;
+    hipError_t e;
+    if (!b.stream && (e = hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking)) != hipSuccess) return e;
+    if (!b.accum_done && (e = hipEventCreateWithFlags(&b.accum_done, hipEventDisableTiming)) != hipSuccess) return e;
+    if (!b.h_hit_count && (e = hipHostMalloc((void **)&b.h_hit_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return e;
+    if (!b.d_hits && (e = hipMalloc(&b.d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return e;
+    if (!b.d_ctrl && (e = hipMalloc(&b.d_ctrl, sizeof(PTControl))) != hipSuccess) return e;
+    if (!b.d_pixel_hit && (e = hipMalloc(&b.d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return e;
+    if (!b.d_pixel_const && (e = hipMalloc(&b.d_pixel_const, npix * sizeof(float4))) != hipSuccess) return e;
+    b.ready = true;
+    return hipSuccess;
+}
+
+void slot_release(BatchSlot &b) {
+    dev_free(b.d_hits); dev_free(b.d_ctrl); dev_free(b.d_pixel_hit); dev_free(b.d_pixel_const); dev_free(b.d_samples); dev_free(b.d_spill);
+    if (b.h_hit_count) { (void)hipHostFree(b.h_hit_count); b.h_hit_count = nullptr; }
+    if (b.accum_done) { (void)hipEventDestroy(b.accum_done); b.accum_done = nullptr; }
+    if (b.stream) { (void)hipStreamDestroy(b.stream); b.stream = nullptr; }
+    b.ready = false; b.sample_slots = 0; b.spill_words = 0; b.primary_epoch = 0; b.queue_clean = false;
+}
+
+/* the overflow area of the traversal stacks, sized for the scene (only trees deeper than the LDS part use it) */
+hipError_t ensure_spill(pt_ctx *c, BatchSlot &b) {
+    const size_t words = c->spill_words ? c->spill_words : 1;
+    if (b.d_spill && b.spill_words >= words) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(b.stream);
+    if (e != hipSuccess) return e;
+    dev_free(b.d_spill); b.spill_words = 0;
+    e = hipMalloc(&b.d_spill, words * sizeof(uint32_t));
+    if (e != hipSuccess) { (void)hipGetLastError(); b.d_spill = nullptr; return e; }
+    b.spill_words = words;
+    return hipSuccess;
+}
 
 /* where a render keeps its per-batch state when that is not the context's own buffers */
 struct WorkBuffers {
@@ -515,7 +604,8 @@ int static_work_buffers(pt_ctx *c, uint32_t n_frames, WorkBuffers &wb) {
                     std::to_string(off + per_frame) + " bytes of scratch, the static array holds " +
                     std::to_string((size_t)PT_STATIC_SCRATCH_BYTES) + " (use pt_render_frames)");
     size_t nb = (PT_STATIC_SCRATCH_BYTES - off) / per_frame;
-    if (nb > 0xffffffffull / slots_per_frame) nb = 0xffffffffull / slots_per_frame;
+    if (nb > 0xffffffffull / (slots_per_frame + 512u * c->params.rays_per_pixel))       /* the queue arithmetic rounds up to eight parts of whole groups */
+        nb = 0xffffffffull / (slots_per_frame + 512u * c->params.rays_per_pixel);
     if (nb > 64) nb = 64;
     if (nb > n_frames) nb = n_frames ? n_frames : 1;
     wb.ctrl = (PTControl *)(base + o_ctrl);
@@ -527,20 +617,42 @@ int static_work_buffers(pt_ctx *c, uint32_t n_frames, WorkBuffers &wb) {
     return PT_OK;
 }
 
-/* Makes d_samples hold at least `slots` float4 values.  The old contents are not kept (a batch writes
+/* Makes the slot's d_samples hold at least `slots` float4 values.  The old contents are not kept (a batch writes
  * every sample it reads).  hipErrorOutOfMemory is returned as such so that the caller can try a smaller batch. */
-hipError_t ensure_sample_slots(pt_ctx *c, size_t slots) {
-    if (slots <= c->sample_slots) return hipSuccess;
-    hipError_t e = hipStreamSynchronize(c->stream);        /* earlier batches may still read the old buffer */
+hipError_t ensure_sample_slots(BatchSlot &b, size_t slots) {
+    if (slots <= b.sample_slots) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(b.stream);        /* earlier batches may still read the old buffer */
     if (e != hipSuccess) return e;
-    dev_free(c->d_samples);
-    c->sample_slots = 0;
-    e = hipMalloc(&c->d_samples, slots * sizeof(float4));
-    if (e != hipSuccess) { (void)hipGetLastError(); c->d_samples = nullptr; return e; }
-    c->sample_slots = slots;
+    dev_free(b.d_samples);
+    b.sample_slots = 0;
+    e = hipMalloc(&b.d_samples, slots * sizeof(float4));
+    if (e != hipSuccess) { (void)hipGetLastError(); b.d_samples = nullptr; return e; }
+    b.sample_slots = slots;
     return hipSuccess;
 }
 
+
+/* The hit count of the slot's primary pass, once its copy has arrived; `wait` blocks for it. */
+hipError_t slot_hit_count(pt_ctx *c, BatchSlot &b, bool wait, bool &known) {
+    known = false;
+    if (b.primary_epoch != c->view_epoch) return hipSuccess;
+    if (b.hit_count_pending) {
+        if (wait) {
+            hipError_t e = hipStreamSynchronize(b.stream);
+            if (e != hipSuccess) return e;
+        } else {
+            hipError_t q = hipStreamQuery(b.stream);
+            if (q == hipErrorNotReady) { (void)hipGetLastError(); return hipSuccess; }
+            if (q != hipSuccess) return q;
+        }
+        b.hit_count = *b.h_hit_count;
+        b.hit_count_pending = false;
+        c->known_hits = b.hit_count;
+        c->known_hits_epoch = c->view_epoch;
+    }
+    known = true;
+    return hipSuccess;
+}
 
 /* wb == nullptr: the context's own buffers, kernels timed with events.  wb != nullptr (the static
  * path): no events either, so that the call creates no runtime object at all. */
@@ -559,19 +671,49 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
         if (by_budget < 1) by_budget = 1;
         if (by_budget < max_batch) max_batch = (uint32_t)by_budget;
     }
+    /* counting contexts run their primary pass exactly once per batch and share one set of counters; the two-paths
+     * schedule shares one set of path buffers: neither is pipelined */
+    const bool may_pipeline = !wb && c->pipeline && !count && !(c->two_paths && c->d_pathbuf);
     /* Frames are rendered in batches: camera and scene are constant within the call, so the
      * primary rays (identical for every sample of every frame, shader.wgsl:80-101) are cast once
      * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
      * and the resolve kernel folds the frames into the accumulation buffer in frame order. */
     for (uint32_t done = 0; done < n_frames;) {
         uint32_t batch = n_frames - done < max_batch ? n_frames - done : max_batch;
+        /* The slot: the one the last batch did NOT use, so that this batch's kernels can start while that one's path
+         * kernel drains - if the sample buffer the batch needs is small (a long batch gains nothing). */
+        int s = 0;
+        if (!wb && !count) {
+            for (int q = 0; q < 2; q++) {       /* pick up hit counts that have arrived, without waiting */
+                bool known;
+                if (c->slot[q].ready) HIP_TRY(c, slot_hit_count(c, c->slot[q], false, known));
+            }
+        }
+        if (may_pipeline) {
+            size_t per_frame = worst_per_frame;
+            if (c->known_hits_epoch == c->view_epoch) per_frame = (((size_t)c->known_hits + 63) / 64 * 64) * rpp;
+            if (per_frame * batch * sizeof(float4) <= c->pipeline_bytes) s = c->last_slot ^ 1;
+        }
+        if (!c->slot[s].ready) {
+            hipError_t e = slot_prepare(c, s);
+            if (e == hipErrorOutOfMemory && s == 1) { (void)hipGetLastError(); slot_release(c->slot[1]); c->pipeline = false; continue; }
+            if (e != hipSuccess) return fail_hip(c, e, "batch slot set-up");
+        }
+        BatchSlot &b = c->slot[s];
+        hipStream_t st = b.stream;
+        if (!wb) {
+            hipError_t e = ensure_spill(c, b);
+            if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(stack overflow area)");
+        }
+        /* the primary pass of an earlier batch for the same camera, scene and shard is still good */
+        const bool cached = !wb && !count && b.primary_epoch == c->view_epoch;
         bool by_hit_count = false;
         if (!wb) {
             const size_t worst = worst_per_frame * batch;
-            if (worst > c->sample_slots) {
+            if (worst > b.sample_slots) {
                 /* counting contexts always take the worst case: their primary pass must run exactly once per batch */
                 if (worst * sizeof(float4) <= c->small_sample_bytes || count) {
-                    hipError_t e = ensure_sample_slots(c, worst);
+                    hipError_t e = ensure_sample_slots(b, worst);
                     if (e == hipErrorOutOfMemory && batch > 1) { max_batch = batch / 2; continue; }
                     if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");
                 } else {
@@ -580,53 +722,101 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
             }
         }
         PTKernelParams k;
-        fill_kernel_params(c, first + done * stride, stride, batch, mode, k);
+        fill_kernel_params(c, b, first + done * stride, stride, batch, mode, k);
         if (wb) { k.ctrl = wb->ctrl; k.pixel_hit = wb->pixel_hit; k.pixel_const = wb->pixel_const; k.hits = wb->hits; k.samples = wb->samples; }
-        /* the control words must start at zero; everything else a batch reads it has written itself
-         * (the hit list up to hit_count, pixel_hit of every pixel, pixel_const of miss pixels, one sample
-         * per path), so stale contents of an earlier call are never seen */
-        HIP_TRY(c, hipMemsetAsync(k.ctrl, 0, sizeof(PTControl), c->stream));
-        if (c->shard_world > 1)     /* pixels of other ranks: marked "not mine" (0xfefefefe), the primary kernel visits owned tiles only */
-            HIP_TRY(c, hipMemsetAsync(k.pixel_hit, 0xfe, npix * sizeof(uint32_t), c->stream));
+        if (cached) {
+            /* only the queue heads start again (the last resolve kernel has seen to that, unless a call failed half
+             * way); hit list, hit count and per-pixel tables stay */
+            if (!b.queue_clean) HIP_TRY(c, hipMemsetAsync(&k.ctrl->queue_head[0], 0, sizeof(k.ctrl->queue_head), st));
+        } else {
+            /* the control words must start at zero; everything else a batch reads it has written itself
+             * (the hit list up to hit_count, pixel_hit of every pixel, pixel_const of miss pixels, one sample
+             * per path), so stale contents of an earlier call are never seen */
+            HIP_TRY(c, hipMemsetAsync(k.ctrl, 0, sizeof(PTControl), st));
+            if (c->shard_world > 1)     /* pixels of other ranks: marked "not mine" (0xfefefefe), the primary kernel visits owned tiles only */
+                HIP_TRY(c, hipMemsetAsync(k.pixel_hit, 0xfe, npix * sizeof(uint32_t), st));
+        }
         if (wb) {
-            HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream));
-            HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream));
-            HIP_TRY(c, pt_launch_resolve(k, c->stream));
+            HIP_TRY(c, pt_launch_primary(k, exact, count, false, st));
+            HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, 0, st));
+            HIP_TRY(c, accum_wait(c, s));
+            HIP_TRY(c, pt_launch_resolve(k, st));
+            HIP_TRY(c, accum_mark(c, s));
             done += batch;
             continue;
         }
-        { Timed t(c, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, c->stream)); t.done(); }
+        bool copy_hit_count = false;
+        if (!cached) {
+            b.primary_epoch = 0;
+            { Timed t(c, st, 0); HIP_TRY(c, pt_launch_primary(k, exact, count, false, st)); t.done(); }
+            b.hit_count_pending = false;
+            copy_hit_count = !count;        /* the tables count as kept once the copy of their hit count is enqueued */
+        }
         if (by_hit_count) {
-            /* a large render: wait for the primary pass and make room for the paths of the pixels it hit */
-            HIP_TRY(c, hipMemcpyAsync(c->h_hit_count, &c->d_ctrl->hit_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            const size_t hits = *c->h_hit_count;
+            /* a large render: size the buffer by the pixels the primary pass hit (waiting for that pass if its
+             * count is not known yet) */
+            if (copy_hit_count) {
+                HIP_TRY(c, hipMemcpyAsync(b.h_hit_count, &b.d_ctrl->hit_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                b.hit_count_pending = true; b.primary_epoch = c->view_epoch;
+                copy_hit_count = false;
+            }
+            bool known = false;
+            HIP_TRY(c, slot_hit_count(c, b, true, known));
+            if (!known) return fail(c, PT_ESTATE, "internal: the hit count of the primary pass is not available");
+            const size_t hits = b.hit_count;
             size_t need = ((hits + 63) / 64 * 64) * rpp * batch;
-            if (need > c->sample_slots) {
+            if (need > b.sample_slots) {
                 size_t want = need + need / 8;              /* headroom: a camera move changes the hit count */
                 const size_t worst = worst_per_frame * batch;
                 if (want > worst) want = worst;
-                hipError_t e = ensure_sample_slots(c, want);
-                if (e == hipErrorOutOfMemory && want > need) e = ensure_sample_slots(c, need);
+                hipError_t e = ensure_sample_slots(b, want);
+                if (e == hipErrorOutOfMemory && want > need) e = ensure_sample_slots(b, need);
                 if (e == hipErrorOutOfMemory && batch > 1) {
-                    /* start this batch again with half the frames (the primary pass does not depend on
-                     * the batch length except for the work counters, which such contexts do not keep) */
+                    /* start this batch again with half the frames; the primary pass that has just run is kept */
                     max_batch = batch / 2;
-                    /* the primary pass runs again for the shorter batch: its first timing is dropped, not counted twice */
-                    if (!c->pending.empty() && c->pending.back().kind == 0) { c->free_events.push_back(c->pending.back()); c->pending.pop_back(); }
+                    c->last_slot = s;
                     continue;
                 }
                 if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");
-                k.samples = c->d_samples;
+            }
+            k.samples = b.d_samples;
+        }
+        /* The size of the persistent grid, when the number of paths is known (a kept primary pass).  A render of
+         * few paths gets a grid that gives every lane about eight of them: filling 1536 blocks costs more than
+         * they are worth then.  A batch that will share the GPU with the batch before it (that one is still
+         * running on the other stream) takes fewer blocks per CU the shorter it is: two grids side by side pass
+         * the CUs to each other smoothly, and the shorter a kernel, the larger the part of its life its drain is.
+         * Measured, 1080p: 16 M paths 2.73 / 2.57 / 2.50 / 2.45 ms per render with 6 / 5 / 4 / 3 blocks per CU,
+         * 33 M paths 9.74 / 9.64 / 9.80 / 9.88, 271 M paths 43.05 / 43.21 / 43.82 / 44.15. */
+        int grid_cap = 0;
+        if (c->adapt_grid && c->known_hits_epoch == c->view_epoch) {
+            const unsigned long long paths = (unsigned long long)c->known_hits * rpp * batch;
+            const unsigned long long lanes_per_block_row = (unsigned long long)c->num_cus * 256u;     /* one block on every CU */
+            const unsigned long long full = lanes_per_block_row * (unsigned)pt_path_blocks_per_cu_max();
+            if (paths < 8u * full) {
+                grid_cap = (int)((paths + 8u * lanes_per_block_row - 1) / (8u * lanes_per_block_row));
+                if (grid_cap < 1) grid_cap = 1;
+            } else if (s != c->last_slot && c->slot[c->last_slot].stream && hipStreamQuery(c->slot[c->last_slot].stream) == hipErrorNotReady) {
+                (void)hipGetLastError();
+                grid_cap = paths < 64u * full ? 4 : paths < 256u * full ? 5 : 0;
             }
         }
-        { Timed t(c, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, c->stream)); t.done(); }
-        { Timed t(c, 2); HIP_TRY(c, pt_launch_resolve(k, c->stream)); t.done(); }
+        b.queue_clean = false;
+        { Timed t(c, st, 1); HIP_TRY(c, pt_launch_paths(k, exact, count, c->num_cus, grid_cap, st)); t.done(); }
+        HIP_TRY(c, accum_wait(c, s));
+        { Timed t(c, st, 2); HIP_TRY(c, pt_launch_resolve(k, st)); t.done(); }
+        b.queue_clean = true;
+        HIP_TRY(c, accum_mark(c, s));
+        if (copy_hit_count) {       /* behind the batch, where nothing waits for it */
+            HIP_TRY(c, hipMemcpyAsync(b.h_hit_count, &b.d_ctrl->hit_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            b.hit_count_pending = true; b.primary_epoch = c->view_epoch;
+        }
+        c->last_slot = s;
         c->timing.frames += batch;
         c->timing.batches++;
         done += batch;
         if (c->pending.size() > 3000) {       /* bound the number of live events on long renders */
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, sync_all(c));
             int rc = drain_events(c);
             if (rc) return rc;
         }
@@ -692,6 +882,9 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (const char *e = getenv("PT_QUAD_FETCH")) c->quad_fetch = atoi(e) != 0;
     if (const char *e = getenv("PT_TWO_PATHS")) c->two_paths = atoi(e) != 0;
     if (const char *e = getenv("PT_STARVE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->starve_min = (uint32_t)v; }
+    if (const char *e = getenv("PT_PIPELINE")) c->pipeline = atoi(e) != 0;
+    if (const char *e = getenv("PT_ADAPT_GRID")) c->adapt_grid = atoi(e) != 0;
+    if (const char *e = getenv("PT_PIPELINE_MB")) { long v = atol(e); if (v >= 0) c->pipeline_bytes = (size_t)v << 20; }
     if (const char *e = getenv("PT_LEAF_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 6) c->leaf_shift = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }
     auto bail = [&](hipError_t he, const char *what) {
@@ -706,13 +899,12 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
         { fail(nullptr, PT_EHIP, std::string("unsupported GPU architecture ") + prop.gcnArchName + " (built for gfx950)"); pt_destroy(c); return PT_EHIP; }
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = static_scratch_lookup(device_ordinal)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+    if ((e = slot_prepare(c, 0)) != hipSuccess) return bail(e, "batch slot set-up (stream, hit list, per-pixel tables)");
+    c->stream = c->slot[0].stream;
     const size_t npix = (size_t)params->width * params->height;
     if ((e = hipMalloc(&c->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
     if ((e = hipMemsetAsync(c->d_accum_own, 0, npix * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset(accum)");
     c->d_accum = c->d_accum_own;
-    if ((e = hipMalloc(&c->d_hits, npix * sizeof(PTHitRecord))) != hipSuccess) return bail(e, "hipMalloc(hits)");
-    if ((e = hipMalloc(&c->d_ctrl, sizeof(PTControl))) != hipSuccess) return bail(e, "hipMalloc(ctrl)");
     /* The sample buffer (one float4 per path of a batch of frames) is allocated by the render calls, for the
      * frames actually asked for; here only its limits are fixed: at most PT_SAMPLE_BUDGET_MB (default 64 GiB
      * of the 288 GB) and 64 frames per batch, and slot numbers must fit 32 bits. */
@@ -721,22 +913,19 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
         if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
         c->sample_budget = budget;
         if (const char *ev = getenv("PT_SMALL_SAMPLE_MB")) { long v = atol(ev); if (v >= 0) c->small_sample_bytes = (size_t)v << 20; }
-        /* hit pixels are stored in interleaved groups of 64; the path kernel's queue arithmetic goes up to
-         * (hit pixels + 7) * frames * rays_per_pixel */
-        const size_t slots_per_frame = ((npix + 63) / 64 * 64 + 8) * params->rays_per_pixel;
+        /* hit pixels are stored in interleaved groups of 64; the path kernel's queue arithmetic (eight parts of
+         * whole groups) goes up to (hit pixels + 8 * 64) * frames * rays_per_pixel */
+        const size_t slots_per_frame = ((npix + 63) / 64 * 64 + 512) * params->rays_per_pixel;
         size_t nb = 0xffffffffull / slots_per_frame;
         if (nb < 1) { fail(nullptr, PT_EINVAL, "width * height * rays_per_pixel does not fit the 32-bit sample numbering"); pt_destroy(c); return PT_EINVAL; }
         if (nb > 64) nb = 64;
         if (const char *ev = getenv("PT_MAX_BATCH")) { long v = atol(ev); if (v >= 1 && (size_t)v < nb) nb = (size_t)v; }
         c->batch_cap = (uint32_t)nb;
     }
-    if ((e = hipHostMalloc((void **)&c->h_hit_count, sizeof(uint32_t), hipHostMallocDefault)) != hipSuccess) return bail(e, "hipHostMalloc(hit count)");
-    if ((e = hipMalloc(&c->d_pixel_hit, npix * sizeof(uint32_t))) != hipSuccess) return bail(e, "hipMalloc(pixel_hit)");
-    if ((e = hipMalloc(&c->d_pixel_const, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(pixel_const)");
     if (c->two_paths && (e = hipMalloc(&c->d_pathbuf, pt_pathbuf_bytes(c->num_cus))) != hipSuccess) return bail(e, "hipMalloc(pathbuf)");
     if ((e = hipMalloc(&c->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail(e, "hipMalloc(counters)");
     if ((e = hipMemsetAsync(c->d_counters, 0, 24 * sizeof(unsigned long long), c->stream)) != hipSuccess) return bail(e, "hipMemset(counters)");
-    if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail(e, "hipStreamSynchronize");
+    if ((e = sync_all(c)) != hipSuccess) return bail(e, "hipStreamSynchronize");
     *out = c;
     return PT_OK;
 }
@@ -775,9 +964,11 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     }
 
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->scene_loaded = false;
-    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_spill);
+    c->view_epoch++;
+    dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big);
+    for (BatchSlot &b : c->slot) { dev_free(b.d_spill); b.spill_words = 0; }
     dev_free(c->d_wide); dev_free(c->d_refit_order); dev_free(c->d_tri9);
     c->refit_ok = false; c->refit_level_begin.clear();
     c->wide_count = 0;
@@ -797,9 +988,11 @@ int pt_upload_scene(pt_ctx *c, const float *spheres, uint32_t sphere_count,
     HIP_TRY(c, hipMalloc(&c->d_spheres, n_sph * 12 * sizeof(float)));
     if (sphere_count)
         HIP_TRY(c, hipMemcpy(c->d_spheres, spheres, (size_t)sphere_count * 12 * sizeof(float), hipMemcpyHostToDevice));
-    {   /* overflow area of the path kernel's traversal stacks (only trees deeper than its LDS part) */
-        size_t words = (size_t)pt_spill_entries((uint32_t)(wide_need > need ? wide_need : need)) * pt_lane_stride(c->num_cus);
-        HIP_TRY(c, hipMalloc(&c->d_spill, (words ? words : 1) * sizeof(uint32_t)));
+    {   /* overflow area of the path kernel's traversal stacks (only trees deeper than its LDS part); the second
+         * slot's is made by the first batch that uses that slot */
+        c->spill_words = (size_t)pt_spill_entries((uint32_t)(wide_need > need ? wide_need : need)) * pt_lane_stride(c->num_cus);
+        hipError_t es = ensure_spill(c, c->slot[0]);
+        if (es != hipSuccess) return fail_hip(c, es, "hipMalloc(stack overflow area)");
     }
     if (rp.big.empty()) rp.big.assign(1, 0);
     HIP_TRY(c, hipMalloc(&c->d_big, rp.big.size() * sizeof(uint32_t)));
@@ -848,13 +1041,11 @@ int pt_rebuild_scene(pt_ctx *c, const float *triangles, uint32_t triangle_count,
         pt_resident_tree_free(t);
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(t.depth) + " exceeds the supported traversal stack");
     }
-    hipError_t e = hipStreamSynchronize(c->stream);
+    hipError_t e = sync_all(c);
     uint32_t *spill = nullptr;
     float *sph = c->d_spheres;
-    if (e == hipSuccess) {
-        size_t words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);
-        e = hipMalloc(&spill, (words ? words : 1) * sizeof(uint32_t));
-    }
+    const size_t spill_words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);
+    if (e == hipSuccess) e = hipMalloc(&spill, (spill_words ? spill_words : 1) * sizeof(uint32_t));
     if (e == hipSuccess && !sph) e = hipMalloc(&sph, 12 * sizeof(float));      /* no scene before: no spheres */
     if (e != hipSuccess) {
         pt_resident_tree_free(t);
@@ -865,9 +1056,12 @@ int pt_rebuild_scene(pt_ctx *c, const float *triangles, uint32_t triangle_count,
     pt_scratch_give_back(c->device, c->d_inner, c->bytes_inner); pt_scratch_give_back(c->device, c->d_tris, c->bytes_tris);
     pt_scratch_give_back(c->device, c->d_big, c->bytes_big); pt_scratch_give_back(c->device, c->d_refit_order, c->bytes_refit_order);
     c->d_inner = nullptr; c->d_tris = nullptr; c->d_big = nullptr; c->d_refit_order = nullptr;
-    dev_free(c->d_spill); dev_free(c->d_tri9);
+    for (BatchSlot &b : c->slot) { dev_free(b.d_spill); b.spill_words = 0; }
+    dev_free(c->d_tri9);
+    c->spill_words = spill_words; c->slot[0].d_spill = spill; c->slot[0].spill_words = spill_words ? spill_words : 1;
+    c->view_epoch++;
     c->bytes_inner = t.bytes_inner; c->bytes_tris = t.bytes_tris; c->bytes_big = t.bytes_big; c->bytes_refit_order = t.bytes_refit_order;
-    c->d_inner = t.d_inner; c->d_tris = t.d_tris; c->d_big = t.d_big; c->d_refit_order = t.d_refit_order; c->d_spill = spill; c->d_spheres = sph;
+    c->d_inner = t.d_inner; c->d_tris = t.d_tris; c->d_big = t.d_big; c->d_refit_order = t.d_refit_order; c->d_spheres = sph;
     c->refit_level_begin = t.refit_level_begin;
     c->refit_ok = true; c->refit_why.clear();
     c->tri_count = triangle_count; c->node_count = t.node_count;
@@ -892,6 +1086,8 @@ int pt_refit_scene(pt_ctx *c, const float *triangles) {
         if ((u & 0x7f800000u) == 0x7f800000u) return fail(c, PT_EINVAL, "a triangle coordinate is not finite");
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, sync_all(c));            /* batches in flight on either stream read the records this call rewrites */
+    c->view_epoch++;
     if (!c->d_tri9) HIP_TRY(c, hipMalloc(&c->d_tri9, (n_floats ? n_floats : 1) * sizeof(float)));
     if (!c->d_refit_flag) HIP_TRY(c, hipMalloc(&c->d_refit_flag, sizeof(uint32_t)));
     HIP_TRY(c, hipMemcpyAsync(c->d_tri9, triangles, n_floats * sizeof(float), hipMemcpyHostToDevice, c->stream));
@@ -902,7 +1098,7 @@ int pt_refit_scene(pt_ctx *c, const float *triangles) {
                                          c->refit_level_begin[h + 1] - c->refit_level_begin[h], c->d_tri9, c->d_big, c->d_refit_flag, c->stream));
     uint32_t not_tame = 0;
     HIP_TRY(c, hipMemcpyAsync(&not_tame, c->d_refit_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     c->fast_div = !not_tame && getenv("PT_NO_FAST_DIV") == nullptr;
     return PT_OK;
 }
@@ -923,7 +1119,11 @@ int pt_load_scene_files(pt_ctx *c, const char *triangles_bin, const char *bvh_bi
 int pt_set_camera(pt_ctx *c, const float position[3], const float rotation_degrees[3]) {
     if (!c) return PT_EINVAL;
     if (!position || !rotation_degrees) return fail(c, PT_EINVAL, "camera pointer is NULL");
+    bool moved = false;      /* compared as bits: a NaN or a change of a zero's sign counts as a move */
+    for (int i = 0; i < 3; i++)
+        moved = moved || memcmp(&c->cam_pos[i], &position[i], sizeof(float)) != 0 || memcmp(&c->cam_rot[i], &rotation_degrees[i], sizeof(float)) != 0;
     for (int i = 0; i < 3; i++) { c->cam_pos[i] = position[i]; c->cam_rot[i] = rotation_degrees[i]; }
+    if (moved) c->view_epoch++;       /* the primary pass of the next batch runs again */
     return PT_OK;
 }
 
@@ -968,6 +1168,7 @@ int pt_render_frames_sum(pt_ctx *c, uint32_t first_frame_count, uint32_t n_frame
 int pt_set_pixel_shard(pt_ctx *c, uint32_t rank, uint32_t world_size) {
     if (!c) return PT_EINVAL;
     if (world_size == 0 || rank >= world_size || world_size > 4096) return fail(c, PT_EINVAL, "need 0 <= rank < world_size <= 4096");
+    if (c->shard_rank != rank || c->shard_world != world_size) c->view_epoch++;
     c->shard_rank = rank; c->shard_world = world_size;
     return PT_OK;
 }
@@ -975,7 +1176,9 @@ int pt_set_pixel_shard(pt_ctx *c, uint32_t rank, uint32_t world_size) {
 int pt_scale_accum(pt_ctx *c, float s) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, accum_wait(c, 0));
     HIP_TRY(c, pt_launch_scale(c->d_accum, c->params.width * c->params.height, s, c->stream));
+    HIP_TRY(c, accum_mark(c, 0));
     return PT_OK;
 }
 
@@ -984,7 +1187,7 @@ int pt_read_accum(pt_ctx *c, float *out, uint32_t stride_floats) {
     if (!out || (stride_floats != 3 && stride_floats != 4)) return fail(c, PT_EINVAL, "out is NULL or stride_floats is not 3 or 4");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npix = (size_t)c->params.width * c->params.height;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (stride_floats == 4) {
         HIP_TRY(c, hipMemcpy(out, c->d_accum, npix * sizeof(float4), hipMemcpyDeviceToHost));
     } else {
@@ -1000,7 +1203,7 @@ int pt_write_accum(pt_ctx *c, const float *in, uint32_t stride_floats) {
     if (!in || (stride_floats != 3 && stride_floats != 4)) return fail(c, PT_EINVAL, "in is NULL or stride_floats is not 3 or 4");
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t npix = (size_t)c->params.width * c->params.height;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (stride_floats == 4) {
         HIP_TRY(c, hipMemcpy(c->d_accum, in, npix * sizeof(float4), hipMemcpyHostToDevice));
     } else {
@@ -1014,14 +1217,16 @@ int pt_write_accum(pt_ctx *c, const float *in, uint32_t stride_floats) {
 int pt_reset_accum(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, accum_wait(c, 0));
     HIP_TRY(c, hipMemsetAsync(c->d_accum, 0, (size_t)c->params.width * c->params.height * sizeof(float4), c->stream));
+    HIP_TRY(c, accum_mark(c, 0));
     return PT_OK;
 }
 
 int pt_bind_accum(pt_ctx *c, void *device_ptr) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     if (!device_ptr) { c->d_accum = c->d_accum_own; return PT_OK; }
     if (((uintptr_t)device_ptr & 15u) != 0) return fail(c, PT_EINVAL, "accumulation buffer must be 16-byte aligned");
     hipPointerAttribute_t attr;
@@ -1044,9 +1249,9 @@ int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
     if (!c->d_ids) HIP_TRY(c, hipMalloc(&c->d_ids, npix * sizeof(int32_t)));
     if (!c->d_dist) HIP_TRY(c, hipMalloc(&c->d_dist, npix * sizeof(float)));
     PTKernelParams k;
-    fill_kernel_params(c, 0, 1, 1, 0, k);
+    fill_kernel_params(c, c->slot[0], 0, 1, 1, 0, k);
     HIP_TRY(c, pt_launch_primary(k, true, false, true, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     HIP_TRY(c, hipMemcpy(prim_id, c->d_ids, npix * sizeof(int32_t), hipMemcpyDeviceToHost));
     HIP_TRY(c, hipMemcpy(distance, c->d_dist, npix * sizeof(float), hipMemcpyDeviceToHost));
     return PT_OK;
@@ -1067,9 +1272,9 @@ int pt_probe_functions(pt_ctx *c, const uint32_t *seeds, const float *dirs, cons
         rc = fail(c, PT_EHIP, hipGetErrorString(e));
     } else {
         PTKernelParams k;
-        fill_kernel_params(c, 0, 1, 1, 0, k);
+        fill_kernel_params(c, c->slot[0], 0, 1, 1, 0, k);
         if ((e = pt_launch_probe(k, (c->params.flags & PT_FLAG_EXACT_MATH) != 0, d_seeds, d_dirs, normal, n, d_out, c->stream)) != hipSuccess ||
-            (e = hipStreamSynchronize(c->stream)) != hipSuccess ||
+            (e = sync_all(c)) != hipSuccess ||
             (e = hipMemcpy(out, d_out, (size_t)n * 64, hipMemcpyDeviceToHost)) != hipSuccess)
             rc = fail(c, PT_EHIP, hipGetErrorString(e));
     }
@@ -1091,7 +1296,7 @@ int pt_probe_intersections(pt_ctx *c, const float *rays, const float *boxes, con
     for (int k = 0; k < 5 && e == hipSuccess; k++) e = hipMalloc(&d[k], sizes[k]);
     for (int k = 0; k < 4 && e == hipSuccess; k++) e = hipMemcpy(d[k], src[k], sizes[k], hipMemcpyHostToDevice);
     if (e == hipSuccess) e = pt_launch_probe_intersections(d[0], d[1], d[2], d[3], n, d[4], c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = sync_all(c);
     if (e == hipSuccess) e = hipMemcpy(out, d[4], sizes[4], hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = fail(c, PT_EHIP, hipGetErrorString(e));
     for (int k = 0; k < 5; k++) dev_free(d[k]);
@@ -1101,7 +1306,7 @@ int pt_probe_intersections(pt_ctx *c, const float *rays, const float *boxes, con
 int pt_synchronize(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     return PT_OK;
 }
 
@@ -1110,7 +1315,7 @@ int pt_get_counters(pt_ctx *c, pt_counters *out) {
     if (!out) return fail(c, PT_EINVAL, "out is NULL");
     if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     unsigned long long h[8];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     out->ray_casts = h[0]; out->box_tests = h[1]; out->tri_tests = h[2]; out->paths = h[3];
@@ -1123,7 +1328,7 @@ int pt_get_debug_stats(pt_ctx *c, uint64_t out[16]) {
     if (!out) return fail(c, PT_EINVAL, "out is NULL");
     if (!(c->params.flags & PT_FLAG_COUNT_WORK)) return fail(c, PT_ESTATE, "context was created without PT_FLAG_COUNT_WORK");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     unsigned long long h[24];
     HIP_TRY(c, hipMemcpy(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < 8; i++) out[i] = h[8 + i];
@@ -1150,7 +1355,7 @@ int pt_get_timing(pt_ctx *c, pt_timing *out) {
     if (!c) return PT_EINVAL;
     if (!out) return fail(c, PT_EINVAL, "out is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     int rc = drain_events(c);
     if (rc) return rc;
     *out = c->timing;
@@ -1160,7 +1365,7 @@ int pt_get_timing(pt_ctx *c, pt_timing *out) {
 int pt_reset_timing(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_all(c));
     int rc = drain_events(c);
     if (rc) return rc;
     c->timing = pt_timing{};
@@ -1179,16 +1384,16 @@ int pt_scene_info(pt_ctx *c, uint32_t *bvh_depth, uint32_t *inner_nodes, uint32_
 void pt_destroy(pt_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)sync_all(c);
     for (EventPair &ep : c->pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     for (EventPair &ep : c->free_events) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     dev_free(c->d_inner); dev_free(c->d_tris); dev_free(c->d_spheres); dev_free(c->d_big); dev_free(c->d_wide);
-    dev_free(c->d_accum_own); dev_free(c->d_hits); dev_free(c->d_ctrl); dev_free(c->d_samples);
+    dev_free(c->d_accum_own);
     dev_free(c->d_counters); dev_free(c->d_ids); dev_free(c->d_dist);
-    dev_free(c->d_pixel_hit); dev_free(c->d_pixel_const); dev_free(c->d_spill); dev_free(c->d_pathbuf);
+    dev_free(c->d_pathbuf);
     dev_free(c->d_refit_order); dev_free(c->d_tri9); dev_free(c->d_refit_flag);
-    if (c->h_hit_count) (void)hipHostFree(c->h_hit_count);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (BatchSlot &b : c->slot) slot_release(b);
+    c->stream = nullptr;
     delete c;
 }
 

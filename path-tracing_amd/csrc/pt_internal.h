@@ -63,11 +63,20 @@ static inline PTFastDiv pt_fastdiv_make(uint32_t d) {
 }
 
 /* control words in device memory, zeroed before each batch of frames */
+/* The path kernel's work queue has PT_QUEUE_PARTS heads (a multiple of 8, at most 64: PT_QUEUE_PARTS / 8 per XCD),
+ * PT_HEAD_STRIDE words apart: every wave makes one atomic per round on a head, and atomics on one cache line - one
+ * memory channel - are served one after the other (with eight heads in one line the benchmark scenes were bound by
+ * exactly that). */
+#ifndef PT_QUEUE_PARTS
+#define PT_QUEUE_PARTS 32
+#endif
+#ifndef PT_HEAD_STRIDE
+#define PT_HEAD_STRIDE 64
+#endif
 struct PTControl {
     uint32_t hit_count;     /* number of PTHitRecord written by the primary kernel */
-    uint32_t pad0;
-    uint32_t queue_head[8]; /* path-kernel work queue heads, one per XCD part */
-    uint32_t pad[6];
+    uint32_t pad0[PT_HEAD_STRIDE - 1];
+    uint32_t queue_head[PT_QUEUE_PARTS * PT_HEAD_STRIDE];   /* head of part p: queue_head[p * PT_HEAD_STRIDE] */
 };
 
 struct PTKernelParams {
@@ -123,8 +132,11 @@ struct PTKernelParams {
 /* launchers implemented in pt_kernels.hip; kp.stack_entries sizes the LDS traversal stacks */
 hipError_t pt_launch_primary(const PTKernelParams &kp, bool exact_math,
                              bool count_work, bool aov_only, hipStream_t stream);
+/* blocks_per_cu_cap: 0 = as many blocks per CU as stay resident (the persistent grid), else at most that many */
 hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact_math,
-                           bool count_work, int num_cus, hipStream_t stream);
+                           bool count_work, int num_cus, int blocks_per_cu_cap, hipStream_t stream);
+/* blocks per CU of the path kernel's full grid */
+int pt_path_blocks_per_cu_max(void);
 hipError_t pt_launch_resolve(const PTKernelParams &kp, hipStream_t stream);
 hipError_t pt_launch_scale(float4 *accum, uint32_t n_pixels, float s, hipStream_t stream);
 hipError_t pt_launch_probe_intersections(const float *rays, const float *boxes, const float *tris, const float *spheres,

@@ -823,10 +823,15 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
     const uint32_t rpp = P.rays_per_pixel;
     const uint32_t per_hit = P.batch_frames * rpp;
     const uint32_t total = P.ctrl->hit_count * per_hit;
-    const uint32_t part = ((P.ctrl->hit_count + 7u) / 8u) * per_hit;     /* whole pixels per part */
+    /* The queue is cut into PT_QUEUE_PARTS equal, contiguous parts of whole pixels, each with a head of its own;
+     * PT_QUEUE_PARTS / 8 consecutive parts belong to one XCD (consecutive paths belong to neighbouring pixels, so an
+     * XCD's parts are a compact piece of the image and the BVH nodes its rays visit stay in that XCD's 4 MiB L2). */
+    const uint32_t part = ((P.ctrl->hit_count + PT_QUEUE_PARTS - 1u) / PT_QUEUE_PARTS) * per_hit;
     /* XCC_ID: bits 3:0 of hardware register 20 */
-    uint32_t queue = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
-    uint32_t queues_done = 0;
+    const uint32_t xcd = P.xcd_queues ? (__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 7u) : (blockIdx.x & 7u);
+    const uint32_t wave_in_xcd = (blockIdx.x >> 3) * PT_PATH_WAVES_PER_BLOCK + wave;      /* blocks go round the XCDs */
+    uint32_t queue = xcd * (PT_QUEUE_PARTS / 8u) + wave_in_xcd % (PT_QUEUE_PARTS / 8u);
+    bool part_done = false;      /* the part in hand has no paths left */
     Counters cn = {0, 0, 0, 0};
 
     /* the lane's phase, one flag each (the compiler keeps them as lane masks in scalar registers) */
@@ -865,53 +870,69 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel(P
                 idle = true;
             }
         }
-        /* (B) idle lanes pull new paths: one atomic per wave.  The queue is cut into 8 equal,
-         * contiguous parts, one per XCD (consecutive paths belong to neighbouring pixels, so a
-         * part is a compact piece of the image and the BVH nodes its rays visit stay in that
-         * XCD's 4 MiB L2).  A wave drains its own XCD's part first, then helps the others.
-         * A new path starts as "cast complete" at its primary hit, iteration i = 0 of trace
-         * (shader.wgsl:117-127), and is shaded below together with the others. */
+        /* (B) idle lanes pull new paths: one atomic per wave and round, on the head of the part the wave works on
+         * (a part of its own XCD while one has paths left, then it helps the others).  The paths a round takes are
+         * consecutive samples of one pixel or of two neighbours: they start their first cast in step.  (Runs of
+         * 64 to 1024 paths per atomic, handed out over several rounds, were measured too: a round then often mixes
+         * the end of one run with the start of another, far away in the image, and 35 to 37.5 lanes instead of 39 do
+         * an inner visit per step.)  A new path starts as "cast complete" at its primary hit, iteration i = 0 of
+         * trace (shader.wgsl:117-127), and is shaded below together with the others. */
         unsigned long long need = __ballot(idle);
         if (need) {
-            while (!drained) {
+            while (need && !drained) {
+                if (part_done) {
+                    /* The part in hand is used up.  One coherent load shows where every head stands: the wave
+                     * goes on with a part of its own XCD that has paths left, else with any such part (the waves
+                     * spread over the candidates by their number).  The picture may be stale: a part found empty
+                     * after all sends the wave back here. */
+                    part_done = false;
+                    bool has = false;
+                    if (lane_id() < PT_QUEUE_PARTS) {
+                        const uint32_t ps = lane_id() * part < total ? lane_id() * part : total;
+                        const uint32_t pl = (total - ps < part) ? total - ps : part;
+                        has = __hip_atomic_load(&P.ctrl->queue_head[lane_id() * PT_HEAD_STRIDE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pl;
+                    }
+                    const unsigned long long any = __ballot(has);
+                    const unsigned long long own = any & (((1ull << (PT_QUEUE_PARTS / 8u)) - 1ull) << (xcd * (PT_QUEUE_PARTS / 8u)));
+                    unsigned long long pick = own ? own : any;
+                    if (!pick) { drained = true; break; }
+                    for (uint32_t skip = wave_in_xcd % (uint32_t)__popcll(pick); skip; skip--) pick &= pick - 1ull;
+                    queue = (uint32_t)__builtin_ctzll(pick);
+                }
+                /* as many consecutive paths as the wave has idle lanes, from the head of the part: one atomic */
                 const uint32_t q_start = queue * part < total ? queue * part : total;
                 const uint32_t q_len = (total - q_start < part) ? total - q_start : part;
+                const uint32_t n_need = (uint32_t)__popcll(need);
                 uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
-                base = __shfl(base, 0, 64);
-                const bool exhausted = base + (uint32_t)__popcll(need) >= q_len;
-                if (base < q_len && idle) {
-                    const uint32_t local = base + prefix_count(need);
-                    if (local < q_len) {
-                        const uint32_t item = q_start + local;
-                        /* queue index -> (hit pixel, frame of the batch, sample) */
-                        uint32_t hf = fast_div(item, P.div_rpp);
-                        uint32_t s = item - hf * rpp;
-                        uint32_t hi = fast_div(hf, P.div_batch);
-                        slot = sample_slot(hi, item - hi * per_hit, per_hit);
-                        uint32_t frame_count = P.frame_first + (hf - hi * P.batch_frames) * P.frame_stride;
-                        PTHitRecord h = P.hits[hi];
-                        uint32_t py = fast_div(h.pixel, P.div_width);
-                        uint32_t px = h.pixel - py * P.width;
-                        uint32_t pixel_index;
-                        V3 rd;
-                        primary_ray(P, px, py, rd, pixel_index);
-                        raypk_set_od(T.R, ld3(P.cam_pos), rd);
-                        /* shader.wgsl:100 and :121, folded: the frame term is the same for every bounce */
-                        seed = pixel_index + s * 248135u + frame_count * 393939123u;
-                        light = mk(0.0f, 0.0f, 0.0f);
-                        ray_color = mk(1.0f, 1.0f, 1.0f);
-                        i = 0;
-                        hit_t = h.distance; hit_id = h.prim_id;
-                        idle = false;
-                        hit = true;
-                    }
+                if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue * PT_HEAD_STRIDE], n_need);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                part_done = base + n_need >= q_len;
+                const uint32_t local = base + prefix_count(need);
+                if (idle && local < q_len) {
+                    const uint32_t item = q_start + local;
+                    /* queue index -> (hit pixel, frame of the batch, sample) */
+                    uint32_t hf = fast_div(item, P.div_rpp);
+                    uint32_t s = item - hf * rpp;
+                    uint32_t hi = fast_div(hf, P.div_batch);
+                    slot = sample_slot(hi, item - hi * per_hit, per_hit);
+                    uint32_t frame_count = P.frame_first + (hf - hi * P.batch_frames) * P.frame_stride;
+                    PTHitRecord h = P.hits[hi];
+                    uint32_t py = fast_div(h.pixel, P.div_width);
+                    uint32_t px = h.pixel - py * P.width;
+                    uint32_t pixel_index;
+                    V3 rd;
+                    primary_ray(P, px, py, rd, pixel_index);
+                    raypk_set_od(T.R, ld3(P.cam_pos), rd);
+                    /* shader.wgsl:100 and :121, folded: the frame term is the same for every bounce */
+                    seed = pixel_index + s * 248135u + frame_count * 393939123u;
+                    light = mk(0.0f, 0.0f, 0.0f);
+                    ray_color = mk(1.0f, 1.0f, 1.0f);
+                    i = 0;
+                    hit_t = h.distance; hit_id = h.prim_id;
+                    idle = false;
+                    hit = true;
                 }
-                if (exhausted) {
-                    queue = (queue + 1u) & 7u;
-                    if (++queues_done == 8u) drained = true;
-                }
-                if (base < q_len) break;          /* got work (the rest of the lanes retry next round) */
+                need = __ballot(idle);          /* lanes the part had nothing left for: served from another part */
             }
             if (drained && idle) { idle = false; dead = true; }
             if (COUNT && drained && !t_drained) { t_drained = __builtin_amdgcn_s_memtime(); rt_drained = wall_clock64(); }
@@ -1127,7 +1148,7 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_m
                     const uint32_t q_start = queue * part < total ? queue * part : total;
                     const uint32_t q_len = (total - q_start < part) ? total - q_start : part;
                     uint32_t base = 0;
-                    if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue], (uint32_t)__popcll(need));
+                    if (lane_id() == 0) base = atomicAdd(&P.ctrl->queue_head[queue * PT_HEAD_STRIDE], (uint32_t)__popcll(need));
                     base = __shfl(base, 0, 64);
                     const bool exhausted = base + (uint32_t)__popcll(need) >= q_len;
                     if (base < q_len && idle) {
@@ -1240,10 +1261,15 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_m
  * weight 1/(frame_count+1).  One read-modify-write of a pixel per batch.  Thread t finishes hit
  * pixel number t of the hit list (its samples are interleaved with those of the 63 other hit
  * pixels of its wave, see sample_slot) and, independently, pixel t of the image if that is a miss
- * pixel; every pixel is written by exactly one thread. */
+ * pixel; every pixel is written by exactly one thread.
+ * The kernel may share the GPU with the path kernel of the NEXT batch (enqueued on another stream), whose waves
+ * would leave it one issue slot in seven: it raises its own priority, because the batch after that one waits for it.
+ * It also leaves the queue heads at zero for the next path kernel that uses these control words. */
 __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t rpp = P.rays_per_pixel, per_hit = P.batch_frames * rpp;
+    if (t < PT_QUEUE_PARTS) P.ctrl->queue_head[t * PT_HEAD_STRIDE] = 0;
     if (t < P.ctrl->hit_count) {
         const uint32_t pixel = P.hits[t].pixel;
         float4 a4 = P.accum[pixel];
@@ -1434,7 +1460,9 @@ static void launch_paths_variant(const PTKernelParams &kp, bool exact, bool coun
     }
 }
 
-hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, hipStream_t st) {
+int pt_path_blocks_per_cu_max(void) { return PT_PATH_WAVES_PER_EU * 4 / PT_PATH_WAVES_PER_BLOCK; }
+
+hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int num_cus, int blocks_per_cu_cap, hipStream_t st) {
     if (kp.stack_entries < 1 || kp.stack_entries > (uint32_t)pt_max_stack_entries()) return hipErrorInvalidValue;
     if (kp.wide && count) return hipErrorInvalidValue;
     /* Resident blocks per CU are set by the registers (PT_PATH_WAVES_PER_EU waves per SIMD); each block's share of the
@@ -1460,6 +1488,7 @@ hipError_t pt_launch_paths(const PTKernelParams &kp, bool exact, bool count, int
     int per_cu = (int)((160 * 1024 - 512) / lds);
     if (per_cu > by_registers) per_cu = by_registers;
     if (per_cu < 1) per_cu = 1;
+    if (blocks_per_cu_cap >= 1 && blocks_per_cu_cap < per_cu) per_cu = blocks_per_cu_cap;
     if (const char *e = getenv("PT_BLOCKS_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
     dim3 grid(num_cus * per_cu);
     if (coop) {

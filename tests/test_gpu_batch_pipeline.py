@@ -1,0 +1,195 @@
+"""Batches of frames in flight on the GPU: the kept primary pass, the two batch slots (one stream each, resolve
+kernels chained in frame order), the grid sized to the work.  None
+of these may change a bit of the image: everything here is compared with the CPU oracle on the same frames
+(shader.wgsl:99-106 is the accumulation whose order matters), through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(width=96, height=54, rays_per_pixel=3, max_bounce_count=4)
+
+
+def _setup(scenes, n=1):
+    cfg = scenes.config(n, width=KW["width"], height=KW["height"], rays_per_pixel=KW["rays_per_pixel"])
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    return cfg, tris, bvh, scenes.spheres_for(cfg["spheres"])
+
+
+def _renderer(pkg, env=None, **flags):
+    """A context created under an environment (the switches are read by pt_create)."""
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        return pkg.Renderer(pkg.default_params(flags=flags.get("flags", pkg.PT_FLAG_EXACT_MATH), **KW), device=0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, first, n):
+    op = oracle_shared.default_params(**KW)
+    sc = oracle_shared.scene(spheres, tris, bvh)
+    return oracle_shared.render_frames(op, sc, pos, rot, first, n)
+
+
+@pytest.mark.parametrize("env", [{}, {"PT_PIPELINE": "0"}, {"PT_MAX_BATCH": "1"}, {"PT_MAX_BATCH": "2", "PT_PIPELINE_MB": "0"},
+                                 {"PT_ADAPT_GRID": "0"}],
+                         ids=["default", "one-slot", "one-frame-batches", "no-room-to-pipeline", "full-grid"])
+def test_calls_in_a_row_accumulate_like_the_oracle(pkg, scenes, oracle_shared, env):
+    """Seven frames over four calls, enqueued without a synchronisation in between (the batches alternate between
+    the two slots and their resolve kernels must still fold the frames in order), with the hit count known from
+    the third call on (the grid is then sized to the few paths of this small image)."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    with _renderer(pkg, env) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        r.render_frames(0, 2)
+        r.render_frames(2, 1)
+        r.synchronize()
+        r.render_frames(3, 3)
+        r.render_frames(6, 1)
+        got = r.read_accum(4)
+        t = r.timing()
+    want = _oracle_frames(oracle_shared, spheres, tris, bvh, cfg["camera_position"], cfg["camera_rotation"], 0, 7)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+    if env.get("PT_MAX_BATCH") is None:
+        assert t["batches"] == 4
+
+
+def test_primary_pass_is_kept_until_the_view_changes(pkg, scenes, oracle_shared):
+    """The primary pass runs once per slot for a still camera (its kernel time stops growing), again after a move,
+    not again when the same pose is set once more; every image equals the oracle's for its pose."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    pos, rot = list(map(float, cfg["camera_position"])), list(map(float, cfg["camera_rotation"]))
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        for _ in range(2):
+            r.render_frames(0, 1)       # one per slot
+        warm = r.timing()["primary_ms"]
+        assert warm > 0
+        for _ in range(4):
+            r.render_frames(0, 1)
+        r.set_camera(pos, rot)          # the same pose: nothing to redo
+        r.render_frames(0, 2)
+        assert r.timing()["primary_ms"] == warm
+        still = r.read_accum(4)
+        moved_pos = [pos[0] + 3.0, pos[1], pos[2] - 2.0]
+        r.set_camera(moved_pos, rot)
+        r.render_frames(0, 2)
+        assert r.timing()["primary_ms"] > warm
+        moved = r.read_accum(4)
+    want_still = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 2)
+    want_moved = _oracle_frames(oracle_shared, spheres, tris, bvh, moved_pos, rot, 0, 2)
+    assert np.array_equal(bits(still[..., :3]), bits(want_still[..., :3]))
+    assert np.array_equal(bits(moved[..., :3]), bits(want_moved[..., :3]))
+    assert not np.array_equal(bits(still), bits(moved))
+
+
+def test_a_new_scene_or_a_refit_drops_the_kept_primary_pass(pkg, scenes, oracle_shared):
+    """upload_scene and refit_scene change what the primary rays hit: renders after them equal a fresh context's."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    other_tris, other_bvh = scenes.mesh("dragon_8k")
+    pos, rot = cfg["camera_position"], cfg["camera_rotation"]
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        r.render_frames(0, 1); r.render_frames(1, 1); r.render_frames(2, 1)
+        r.upload_scene(spheres, other_tris, other_bvh)
+        r.render_frames(0, 2)
+        after_upload = r.read_accum(4)
+        r.upload_scene(spheres, tris, bvh)
+        r.render_frames(0, 1); r.render_frames(1, 1)
+        squashed = tris.copy()
+        squashed[:, 1::3] *= np.float32(0.5)            # y of every vertex
+        r.refit_scene(squashed)
+        r.render_frames(0, 2)
+        after_refit = r.read_accum(4)
+    with _renderer(pkg) as f:
+        f.upload_scene(spheres, other_tris, other_bvh)
+        f.set_camera(pos, rot)
+        f.render_frames(0, 2)
+        fresh_other = f.read_accum(4)
+        f.upload_scene(spheres, tris, bvh)
+        f.refit_scene(squashed)
+        f.render_frames(0, 2)
+        fresh_refit = f.read_accum(4)
+    assert np.array_equal(bits(after_upload), bits(fresh_other))
+    assert np.array_equal(bits(after_refit), bits(fresh_refit))
+    want = _oracle_frames(oracle_shared, spheres, other_tris, other_bvh, pos, rot, 0, 2)
+    assert np.array_equal(bits(after_upload[..., :3]), bits(want[..., :3]))
+
+
+def test_operations_on_the_accumulation_buffer_keep_their_place_between_batches(pkg, scenes, oracle_shared):
+    """reset, scale and the sum mode are enqueued on the first slot's stream while batches run on both: the order
+    of the calls is the order of the operations on the buffer."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    pos, rot = cfg["camera_position"], cfg["camera_rotation"]
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        r.render_frames(0, 1); r.render_frames(1, 1); r.render_frames(2, 1)
+        r.reset_accum()
+        r.render_frames_sum(0, 2, 1)
+        r.render_frames_sum(2, 1, 1)
+        r.scale_accum(0.25)
+        r.render_frames_sum(3, 1, 1)
+        got = r.read_accum(4)
+    op = oracle_shared.default_params(**KW)
+    sc = oracle_shared.scene(spheres, tris, bvh)
+    want = oracle_shared.render_frames_sum(op, sc, pos, rot, 0, 2, 1)
+    want = oracle_shared.render_frames_sum(op, sc, pos, rot, 2, 1, 1, accum=want)
+    want[..., :3] *= np.float32(0.25)
+    want = oracle_shared.render_frames_sum(op, sc, pos, rot, 3, 1, 1, accum=want)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
+def test_static_render_after_pipelined_batches(pkg, scenes):
+    """The entry point that allocates nothing runs on the first slot's stream with its own buffers: it continues
+    the running mean the pipelined batches have left, and they continue its."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    with _renderer(pkg) as r, _renderer(pkg, {"PT_PIPELINE": "0"}) as plain:
+        for x in (r, plain):
+            x.upload_scene(spheres, tris, bvh)
+            x.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+        r.render_frames(0, 1); r.render_frames(1, 1); r.render_frames(2, 1)
+        r.render_frames_static(3, 2)
+        r.render_frames(5, 1); r.render_frames(6, 1)
+        plain.render_frames(0, 7)
+        assert np.array_equal(bits(r.read_accum(4)), bits(plain.read_accum(4)))
+
+
+def test_pipelined_full_size_equals_one_slot(pkg, scenes):
+    """Configuration 2 at full size in default math, eight renders in a row on two slots against the same on one."""
+    cfg = scenes.config(2)
+    tris, bvh = scenes.mesh(cfg["mesh"])
+    images = []
+    for env in ({}, {"PT_PIPELINE": "0", "PT_ADAPT_GRID": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            r = pkg.Renderer(pkg.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=cfg["rays_per_pixel"],
+                                                max_bounce_count=cfg["max_bounce_count"]), device=0)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    del os.environ[k]
+                else:
+                    os.environ[k] = v
+        with r:
+            r.upload_scene(scenes.spheres_for(cfg["spheres"]), tris, bvh)
+            r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
+            for k in range(8):
+                r.render_frames(k, 1)
+            images.append(r.read_accum(4))
+    assert np.array_equal(bits(images[0]), bits(images[1]))

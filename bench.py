@@ -350,9 +350,9 @@ def main():
                 other["l2"] = {"achieved": gbs, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": gbs / L2_PEAK_GBS,
                                "l1_hit_rate": d["l1_hit_rate"], "l2_hit_rate": d.get("l2_hit_rate")}
             if "valu_busy_low" in d:
-                other["valu"] = {"frac_low": d["valu_busy_low"] * scale, "frac_high": d["valu_busy_high"] * scale,
+                other["valu"] = {"frac_low": min(1.0, d["valu_busy_low"] * scale), "frac_high": min(1.0, d["valu_busy_high"] * scale),
                                  "lane_utilisation": d["valu_lane_utilisation"],
-                                 "useful": d["valu_busy_high"] * scale * d["valu_lane_utilisation"],
+                                 "useful": min(1.0, d["valu_busy_high"] * scale) * d["valu_lane_utilisation"],
                                  "note": "issue cycles / SIMD cycles; high = SQ_ACTIVE_INST_VALU x 4 cycles (the counter's own busy "
                                          "time), low = SQ_INSTS_VALU x 2 (as if every instruction were a 2-cycle v_fma/v_mul/v_add; "
                                          "packed f32, min/max, compares and selects take 4: tools/ubench/valu_ops); useful = high x "
@@ -362,9 +362,13 @@ def main():
             roof["binding_unit"] = {
                 "scene_resident_in": None if scene_mb is None else ("L2 (4 MiB per XCD)" if scene_mb <= 4.0 else "Infinity Cache (256 MiB)"),
                 "scene_megabytes": scene_mb,
-                "binding": "gather issue and dependent latency of the record fetches in the CUs (address unit busy %.2f, %.2f of the "
-                           "gather ceiling); bandwidth of that level: L2 %.3f, Infinity Cache / HBM %.3f of peak"
-                           % (other.get("address_unit_busy", {}).get("frac", float("nan")), roof["frac"] or float("nan"),
+                "binding": "%s (address unit busy %.2f, %.2f of the gather ceiling; vector ALUs busy %.2f); bandwidth of that "
+                           "level: L2 %.3f, Infinity Cache / HBM %.3f of peak"
+                           % ("the vector ALUs (shading and the sphere tests of every cast) together with the gather issue of the record fetches"
+                              if other.get("valu", {}).get("frac_high", 0) >= other.get("address_unit_busy", {}).get("frac", 0)
+                              else "gather issue and dependent latency of the record fetches in the CUs",
+                              other.get("address_unit_busy", {}).get("frac", float("nan")), roof["frac"] or float("nan"),
+                              other.get("valu", {}).get("frac_high", float("nan")),
                               other.get("l2", {}).get("frac", float("nan")), other.get("hbm", {}).get("frac", float("nan")))}
             roof["other_bounds"] = other
         elif world > 1:

@@ -229,8 +229,17 @@ void *pt_accum_device_ptr(pt_ctx *ctx);
  * width*height elements. */
 int pt_primary_hits(pt_ctx *ctx, int32_t *prim_id, float *distance);
 
-/* Blocks until the stream is idle. */
+/* Blocks until everything the context has enqueued is done. */
 int pt_synchronize(pt_ctx *ctx);
+
+/* Frame pacing.  The render calls only enqueue work (the reference's State::render returns after
+ * queue.submit, src/main.rs:506-508, and the surface lets a frame or two be in flight before
+ * get_current_texture blocks, :466): a host that waits for every frame before it builds the next one
+ * leaves the GPU idle while each path kernel drains.  pt_wait_in_flight(ctx, 1) returns when at most the
+ * batch of frames enqueued last is still running, so the tick loop  set_camera; render_frames(f, 1);
+ * wait_in_flight(1)  always has the next frame queued behind the current one; 0 is pt_synchronize; larger
+ * values return at once (a context runs at most two batches at a time). */
+int pt_wait_in_flight(pt_ctx *ctx, uint32_t max_in_flight);
 
 int pt_get_counters(pt_ctx *ctx, pt_counters *out);  /* synchronises; needs PT_FLAG_COUNT_WORK */
 int pt_reset_counters(pt_ctx *ctx);

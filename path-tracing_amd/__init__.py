@@ -68,7 +68,7 @@ API_SYMBOLS = [
     "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error", "pt_bvh_build_gpu_release_cache", "pt_refit_scene", "pt_rebuild_scene",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
-    "pt_render_frames_static", "pt_static_scratch_bytes",
+    "pt_render_frames_static", "pt_static_scratch_bytes", "pt_wait_in_flight",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -129,6 +129,7 @@ def load_library():
     L.pt_accum_device_ptr.restype = C.c_void_p
     L.pt_primary_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
     L.pt_synchronize.argtypes = [C.c_void_p]
+    L.pt_wait_in_flight.argtypes = [C.c_void_p, C.c_uint32]
     L.pt_get_counters.argtypes = [C.c_void_p, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [C.c_void_p]
     L.pt_get_debug_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -445,6 +446,10 @@ class Renderer:
 
     def synchronize(self):
         self._check(self._L.pt_synchronize(self._ctx))
+
+    def wait_in_flight(self, max_in_flight=1):
+        """pt_wait_in_flight: returns when at most `max_in_flight` batches of frames are still running."""
+        self._check(self._L.pt_wait_in_flight(self._ctx, int(max_in_flight)))
 
     def counters(self):
         c = PtCounters()

@@ -146,7 +146,7 @@ struct pt_ctx {
     int stack_entries = 0;
     bool fast_div = false;
     uint32_t shard_rank = 0, shard_world = 1;
-    uint32_t refill_min = 60;
+    uint32_t refill_min = 48;
     uint32_t quad_fetch = 0;           /* PT_QUAD_FETCH: see PTKernelParams::quad_fetch */
     uint32_t two_paths = 0;            /* PT_TWO_PATHS: see PTKernelParams::two_paths */
     uint32_t starve_min = 16;
@@ -881,6 +881,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (const char *e = getenv("PT_REFILL_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->refill_min = (uint32_t)v; }
     if (const char *e = getenv("PT_QUAD_FETCH")) c->quad_fetch = atoi(e) != 0;
     if (const char *e = getenv("PT_TWO_PATHS")) c->two_paths = atoi(e) != 0;
+    if (c->two_paths && !getenv("PT_REFILL_MIN")) c->refill_min = 60;       /* that schedule shades at 60 waiting lanes */
     if (const char *e = getenv("PT_STARVE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->starve_min = (uint32_t)v; }
     if (const char *e = getenv("PT_PIPELINE")) c->pipeline = atoi(e) != 0;
     if (const char *e = getenv("PT_ADAPT_GRID")) c->adapt_grid = atoi(e) != 0;
@@ -1307,6 +1308,18 @@ int pt_synchronize(pt_ctx *c) {
     if (!c) return PT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, sync_all(c));
+    return PT_OK;
+}
+
+int pt_wait_in_flight(pt_ctx *c, uint32_t max_in_flight) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (max_in_flight == 0) { HIP_TRY(c, sync_all(c)); return PT_OK; }
+    if (max_in_flight >= 2) return PT_OK;
+    /* everything but the batch enqueued last: the other slot's stream (stream 0 also carries the operations that
+     * are no batches; they are short) */
+    BatchSlot &older = c->slot[c->last_slot ^ 1];
+    if (older.stream) HIP_TRY(c, hipStreamSynchronize(older.stream));
     return PT_OK;
 }
 

@@ -308,7 +308,7 @@ __device__ __forceinline__ void trav_begin(const PTKernelParams &P, uint32_t sta
  * Measured on MI355X and rejected: (1) a copy of the top ~1000 records of the tree in LDS (40 % of
  * all visits) - no gain; (2) quad-cooperative record fetches through LDS-DMA - 20 % slower (longer
  * dependent chain per step); (3) prefetching both children while the box tests run - 25 % slower.
- * Probes that add work without changing results (PT_ABL_* below) put the cost of the four 16-byte
+ * Probes that added work without changing results (a second box test, four more loads per visit) put the cost of the four 16-byte
  * loads of a visit at about 27 % of the kernel and that of the two box tests at about 16 %; the
  * loads cost the same whether they hit or miss and whether they fetch 8 or 16 bytes, so it is the
  * number of gather instructions that counts.
@@ -753,19 +753,28 @@ __global__ __launch_bounds__(PT_BLOCK) void primary_kernel(PTKernelParams P) {
         return;
     }
     const bool hit = valid && id != PT_NONE;
-    /* compact the hit pixels of this wave into the global list: one atomic per wave */
+    /* Compact the hit pixels into the global list: ONE atomic per block (every block of the grid makes one on the
+     * same word, and atomics on one word are served one after the other: with one per wave they were most of this
+     * kernel's time).  The waves' counts meet in the first words of the LDS, which the traversal stacks no longer
+     * need. */
     unsigned long long mask = __ballot(hit);
     uint32_t hit_index = PT_PIXEL_MISS;
-    if (mask) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&P.ctrl->hit_count, (uint32_t)__popcll(mask));
-        base = __shfl(base, 0, 64);
-        if (hit) {
-            hit_index = base + prefix_count(mask);
-            PTHitRecord r;
-            r.pixel = pixel; r.prim_id = id; r.distance = t; r.pad = 0;
-            P.hits[hit_index] = r;
-        }
+    __syncthreads();                     /* every wave's traversal is over */
+    if (lane == 0) pt_lds[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (uint32_t w = 0; w < PT_WAVES_PER_BLOCK; w++) n += pt_lds[w];
+        pt_lds[PT_WAVES_PER_BLOCK] = n ? atomicAdd(&P.ctrl->hit_count, n) : 0u;
+    }
+    __syncthreads();
+    if (hit) {
+        uint32_t base = pt_lds[PT_WAVES_PER_BLOCK];
+        for (uint32_t w = 0; w < wave; w++) base += pt_lds[w];
+        hit_index = base + prefix_count(mask);
+        PTHitRecord r;
+        r.pixel = pixel; r.prim_id = id; r.distance = t; r.pad = 0;
+        P.hits[hit_index] = r;
     }
     if (valid) {
         P.pixel_hit[pixel] = hit_index;

@@ -193,3 +193,26 @@ def test_pipelined_full_size_equals_one_slot(pkg, scenes):
                 r.render_frames(k, 1)
             images.append(r.read_accum(4))
     assert np.array_equal(bits(images[0]), bits(images[1]))
+
+
+def test_frame_pacing_with_one_frame_in_flight(pkg, scenes, oracle_shared):
+    """The tick loop of an interactive host: move the camera, enqueue a frame, wait for the frame BEFORE it.  The
+    camera moves every second tick (a move restarts the running mean, src/main.rs:47-49); the buffer after the last
+    tick equals the oracle's for the last pose and the frames rendered at it."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    rot = list(map(float, cfg["camera_rotation"]))
+    pos = list(map(float, cfg["camera_position"]))
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        for tick in range(9):
+            if tick % 2 == 0 and tick < 8:
+                pos = [pos[0] + 0.5, pos[1], pos[2]]
+                r.set_camera(pos, rot)          # frame_count back to 0
+            r.render(1)
+            r.wait_in_flight(1)
+        assert r.frame_count == 3               # ticks 6, 7, 8 at the last pose
+        r.wait_in_flight(0)
+        got = r.read_accum(4)
+    want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 3)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))

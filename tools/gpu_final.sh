@@ -6,7 +6,7 @@ cd "$R"; mkdir -p gpurun_out/final
 timeout -k 10 1100 python3 -u -m pytest tests -m gpu -x -q --timeout 600 --timeout-method thread > gpurun_out/final/gputests.log 2>&1 || { tail -30 gpurun_out/final/gputests.log; exit 1; }
 tail -3 gpurun_out/final/gputests.log
 timeout -k 10 400 python3 bench.py > gpurun_out/final/bench_cfg4.json 2> gpurun_out/final/bench_cfg4.err || { tail gpurun_out/final/bench_cfg4.err; exit 1; }
-for c in 2 3 5; do timeout -k 10 400 python3 bench.py --config $c --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/final/bench_cfg$c.json 2> gpurun_out/final/bench_cfg$c.err || { tail gpurun_out/final/bench_cfg$c.err; exit 1; }; done
+for c in 2 3 5; do S=30; [ $c = 5 ] && S=3; timeout -k 10 400 python3 bench.py --config $c --steps $S --warmup 2 --no-cpu-baseline > gpurun_out/final/bench_cfg$c.json 2> gpurun_out/final/bench_cfg$c.err || { tail gpurun_out/final/bench_cfg$c.err; exit 1; }; done
 PT_BENCH_REHEARSAL=1 timeout -k 10 400 python3 bench.py --gpus 2 --steps 2 --warmup 1 > gpurun_out/final/bench_2rank_rehearsal.json 2> gpurun_out/final/bench_2rank.err || { tail gpurun_out/final/bench_2rank.err; exit 1; }
 python3 - <<'PY'
 import json

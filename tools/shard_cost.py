@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel times of one rank's share under pixel sharding (run alone on a GPU): what bench.py --gpus N
-would see per rank, without the collective.  usage: tools/shard_cost.py [config]"""
-import os, sys
+"""Wall time of one rank's share of a render under both splits (run alone on a GPU, each render followed by the
+synchronisation the collective needs): what bench.py --gpus N would see per rank, without the collective.
+usage: tools/shard_cost.py [config]"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
 pkg = entry.load_package()
@@ -9,18 +10,27 @@ from path_tracing_amd import scenes
 cfg = scenes.config(int(sys.argv[1]) if len(sys.argv) > 1 else 4)
 tris, bvh = scenes.mesh(cfg["mesh"])
 p = pkg.default_params(width=cfg["width"], height=cfg["height"], rays_per_pixel=cfg["rays_per_pixel"], max_bounce_count=cfg["max_bounce_count"])
+K = 6
+n = cfg["n_frames"]
 with pkg.Renderer(p) as r:
     r.upload_scene(scenes.spheres_for(cfg["spheres"]), tris, bvh)
     r.set_camera(cfg["camera_position"], cfg["camera_rotation"])
-    base = None
-    for world in (1, 2, 4, 8):
-        r.set_pixel_shard(0, world)
-        r.render_frames(0, cfg["n_frames"]); r.synchronize(); r.reset_timing()
-        for _ in range(3):
-            r.render_frames(0, cfg["n_frames"])
-        r.synchronize()
-        t = r.timing()
-        tot = (t["primary_ms"] + t["path_ms"] + t["resolve_ms"]) / 3
-        base = base or tot
-        print("world %d: primary %.3f path %.3f resolve %.3f ms per render -> kernel-time efficiency %.1f %%" % (
-            world, t["primary_ms"] / 3, t["path_ms"] / 3, t["resolve_ms"] / 3, 100 * base / world / tot))
+    for split in ("pixels", "frames"):
+        base = None
+        for world in (1, 2, 4, 8):
+            if split == "frames" and n % world:
+                continue
+            r.set_pixel_shard(0, world if split == "pixels" else 1)
+            def once():
+                if split == "pixels":
+                    r.render_frames(0, n)
+                else:
+                    r.render_frames_sum(0, n // world, world)
+                r.synchronize()
+            once(); once()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                once()
+            ms = (time.perf_counter() - t0) / K * 1e3
+            base = base or ms
+            print("%s split, world %d: %.3f ms per render -> efficiency %.1f %% (render time only)" % (split, world, ms, 100 * base / world / ms))

@@ -176,7 +176,7 @@ int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames)
  * (64 MiB) that every GPU the library runs on holds until the process ends, and the call itself
  * calls no hipMalloc / hipFree / hipEventCreate: it only enqueues memsets and kernels on the
  * context's stream.  Scene, camera and accumulation buffer are the context's, as in
- * pt_render_frames.  Needs 256 + 36 * width * height + 16 * roundup64(width * height) *
+ * pt_render_frames.  Needs 8448 + 36 * width * height + 16 * roundup64(width * height) *
  * rays_per_pixel bytes for a one-frame batch (more frames per batch are used when they fit);
  * PT_EINVAL with the two byte counts in the message when that exceeds the array.  The kernels are not
  * timed (pt_get_timing does not see them).  The layout is sized for the worst case (every pixel a hit

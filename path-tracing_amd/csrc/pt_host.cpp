@@ -99,6 +99,8 @@ struct pt_ctx {
     hipStream_t stream = nullptr;      /* = slot[0].stream: everything that is not a batch of frames runs here */
     BatchSlot slot[2];
     int last_slot = 0;                 /* slot of the batch enqueued last */
+    unsigned long long batch_seq = 0;  /* batches enqueued so far */
+    hipEvent_t batch_done[2] = {nullptr, nullptr};     /* recorded behind batch number n in batch_done[n & 1] (pt_wait_in_flight) */
     int accum_last = -1;               /* slot whose stream touched the accumulation buffer last (-1: none yet) */
     unsigned long long view_epoch = 1; /* bumped by whatever changes the primary pass's results */
     bool pipeline = true;              /* PT_PIPELINE=0: every batch on slot 0 */
@@ -673,7 +675,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
     }
     /* counting contexts run their primary pass exactly once per batch and share one set of counters; the two-paths
      * schedule shares one set of path buffers: neither is pipelined */
-    const bool may_pipeline = !wb && c->pipeline && !count && !(c->two_paths && c->d_pathbuf);
+    bool may_pipeline = !wb && c->pipeline && !count && !(c->two_paths && c->d_pathbuf);
     /* Frames are rendered in batches: camera and scene are constant within the call, so the
      * primary rays (identical for every sample of every frame, shader.wgsl:80-101) are cast once
      * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
@@ -696,7 +698,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
         }
         if (!c->slot[s].ready) {
             hipError_t e = slot_prepare(c, s);
-            if (e == hipErrorOutOfMemory && s == 1) { (void)hipGetLastError(); slot_release(c->slot[1]); c->pipeline = false; continue; }
+            if (e == hipErrorOutOfMemory && s == 1) { (void)hipGetLastError(); (void)hipStreamSynchronize(c->slot[1].stream); if (c->accum_last == 1) c->accum_last = -1; slot_release(c->slot[1]); c->pipeline = false; may_pipeline = false; c->last_slot = 0; continue; }
             if (e != hipSuccess) return fail_hip(c, e, "batch slot set-up");
         }
         BatchSlot &b = c->slot[s];
@@ -714,6 +716,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
                 /* counting contexts always take the worst case: their primary pass must run exactly once per batch */
                 if (worst * sizeof(float4) <= c->small_sample_bytes || count) {
                     hipError_t e = ensure_sample_slots(b, worst);
+                    if (e == hipErrorOutOfMemory && s == 1) { c->pipeline = false; may_pipeline = false; continue; }      /* no room for a second slot: go on with one */
                     if (e == hipErrorOutOfMemory && batch > 1) { max_batch = batch / 2; continue; }
                     if (e != hipSuccess) return fail_hip(c, e, "hipMalloc(samples)");
                 } else {
@@ -742,6 +745,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
             HIP_TRY(c, accum_wait(c, s));
             HIP_TRY(c, pt_launch_resolve(k, st));
             HIP_TRY(c, accum_mark(c, s));
+            HIP_TRY(c, hipEventRecord(c->batch_done[c->batch_seq & 1], st));
+            c->batch_seq++;
             done += batch;
             continue;
         }
@@ -771,6 +776,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
                 if (want > worst) want = worst;
                 hipError_t e = ensure_sample_slots(b, want);
                 if (e == hipErrorOutOfMemory && want > need) e = ensure_sample_slots(b, need);
+                if (e == hipErrorOutOfMemory && s == 1) { c->pipeline = false; may_pipeline = false; c->last_slot = s; continue; }
                 if (e == hipErrorOutOfMemory && batch > 1) {
                     /* start this batch again with half the frames; the primary pass that has just run is kept */
                     max_batch = batch / 2;
@@ -811,6 +817,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
             HIP_TRY(c, hipMemcpyAsync(b.h_hit_count, &b.d_ctrl->hit_count, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             b.hit_count_pending = true; b.primary_epoch = c->view_epoch;
         }
+        HIP_TRY(c, hipEventRecord(c->batch_done[c->batch_seq & 1], st));
+        c->batch_seq++;
         c->last_slot = s;
         c->timing.frames += batch;
         c->timing.batches++;
@@ -902,6 +910,8 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if ((e = static_scratch_lookup(device_ordinal)) != hipSuccess) return bail(e, "hipGetSymbolAddress(scratch)");
     if ((e = slot_prepare(c, 0)) != hipSuccess) return bail(e, "batch slot set-up (stream, hit list, per-pixel tables)");
     c->stream = c->slot[0].stream;
+    for (hipEvent_t &ev : c->batch_done)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     const size_t npix = (size_t)params->width * params->height;
     if ((e = hipMalloc(&c->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
     if ((e = hipMemsetAsync(c->d_accum_own, 0, npix * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset(accum)");
@@ -1316,10 +1326,8 @@ int pt_wait_in_flight(pt_ctx *c, uint32_t max_in_flight) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (max_in_flight == 0) { HIP_TRY(c, sync_all(c)); return PT_OK; }
     if (max_in_flight >= 2) return PT_OK;
-    /* everything but the batch enqueued last: the other slot's stream (stream 0 also carries the operations that
-     * are no batches; they are short) */
-    BatchSlot &older = c->slot[c->last_slot ^ 1];
-    if (older.stream) HIP_TRY(c, hipStreamSynchronize(older.stream));
+    /* the batch before the last one (and with it, by the order of the resolve kernels, every batch before that) */
+    if (c->batch_seq >= 2) HIP_TRY(c, hipEventSynchronize(c->batch_done[c->batch_seq & 1]));
     return PT_OK;
 }
 
@@ -1406,6 +1414,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_pathbuf);
     dev_free(c->d_refit_order); dev_free(c->d_tri9); dev_free(c->d_refit_flag);
     for (BatchSlot &b : c->slot) slot_release(b);
+    for (hipEvent_t &ev : c->batch_done) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
     c->stream = nullptr;
     delete c;
 }

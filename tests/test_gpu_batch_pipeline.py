@@ -195,14 +195,15 @@ def test_pipelined_full_size_equals_one_slot(pkg, scenes):
     assert np.array_equal(bits(images[0]), bits(images[1]))
 
 
-def test_frame_pacing_with_one_frame_in_flight(pkg, scenes, oracle_shared):
+@pytest.mark.parametrize("env", [{}, {"PT_PIPELINE": "0"}], ids=["two-slots", "one-slot"])
+def test_frame_pacing_with_one_frame_in_flight(pkg, scenes, oracle_shared, env):
     """The tick loop of an interactive host: move the camera, enqueue a frame, wait for the frame BEFORE it.  The
     camera moves every second tick (a move restarts the running mean, src/main.rs:47-49); the buffer after the last
     tick equals the oracle's for the last pose and the frames rendered at it."""
     cfg, tris, bvh, spheres = _setup(scenes)
     rot = list(map(float, cfg["camera_rotation"]))
     pos = list(map(float, cfg["camera_position"]))
-    with _renderer(pkg) as r:
+    with _renderer(pkg, env) as r:
         r.upload_scene(spheres, tris, bvh)
         r.set_camera(pos, rot)
         for tick in range(9):

@@ -217,3 +217,30 @@ def test_frame_pacing_with_one_frame_in_flight(pkg, scenes, oracle_shared, env):
         got = r.read_accum(4)
     want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 3)
     assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
+def test_overlapping_calls_give_the_same_bits_every_time(pkg, scenes, oracle_shared):
+    """Forty repetitions of: calls of 1, 2, 1, 3 frames, a camera move and back, the same calls again - all enqueued
+    without waiting.  Which batch overlaps which, the order of the hit list and who takes which path vary from run
+    to run; the image may not (and it equals the oracle's seven frames)."""
+    import zlib
+    cfg, tris, bvh, spheres = _setup(scenes)
+    pos, rot = list(map(float, cfg["camera_position"])), list(map(float, cfg["camera_rotation"]))
+    away = [pos[0] + 2.0, pos[1], pos[2]]
+    sums = set()
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        for k in range(40):
+            for where in (pos, away, pos):
+                r.set_camera(where, rot)
+                f = 0
+                for n in ((1,) if where is away else (1, 2, 1, 3)):
+                    r.render_frames(f, n)
+                    f += n
+                    if k % 3 == 0:
+                        r.wait_in_flight(1)
+            img = r.read_accum(4)
+            sums.add(zlib.crc32(img.tobytes()))
+    assert len(sums) == 1
+    want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 7)
+    assert np.array_equal(bits(img[..., :3]), bits(want[..., :3]))

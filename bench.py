@@ -217,16 +217,20 @@ def main():
                     for k in phase:
                         phase[k] += sharded.last_timing[k]
             else:
-                r.render_frames(0, n_frames)          # the reference protocol: running mean over frames
-                r.synchronize()
+                # the reference protocol: running mean over frames.  Like State::render the call only enqueues: the steps
+                # of the timed region run back to back on the GPU (the next render starts while this one drains) and the
+                # region ends with a synchronisation.
+                r.render_frames(0, n_frames)
 
         for _ in range(args.warmup):
             step()
+        r.synchronize()
         r.reset_timing()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step(timed=True)
+        r.synchronize()
         fence()
         elapsed = time.perf_counter() - t0
         timing = r.timing()
@@ -298,11 +302,18 @@ def main():
                 "peak": None, "unit": "G gather instructions/s", "frac": None, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_timed": int(timing["batches"])}
         launches_per_step = timing["batches"] / args.steps     # frames are rendered in batches
-        # Consecutive batches run on two streams: the next launch starts while this one drains, so the launches' own
-        # durations (avg_launch_ms, which the roofline is quoted on, as a profiler would see them) add up to more than
-        # the wall time.
+        # Consecutive launches run on two streams: the next one starts while this one drains, and short ones run side by
+        # side for most of their lives.  Their own durations (avg_launch_ms: HIP events around each launch, what a
+        # profiler's kernel trace shows) then add up to more than the wall time, and "work of one launch / its duration"
+        # would describe half a GPU.  The rates below are therefore taken over rate_launch_ms: the launch's own duration
+        # when launches do not overlap, else the wall time of the timed region per launch (which also holds the resolve
+        # kernels and launch gaps, so the rate is on the low side).
         roof["wall_ms_per_launch"] = elapsed / args.steps * 1e3 / launches_per_step if launches_per_step else None
         roof["launches_overlap"] = bool(launches_per_step and avg_ms > roof["wall_ms_per_launch"])
+        rate_ms = roof["wall_ms_per_launch"] if roof["launches_overlap"] else avg_ms
+        roof["rate_launch_ms"] = rate_ms
+        roof["rate_basis"] = ("wall time of the timed region per launch (launches overlap on two streams)" if roof["launches_overlap"]
+                              else "mean duration of a launch (HIP events on its stream)")
         pfile = "profiles/path_kernel_pmc_cfg%d.json" % args.config
         ppath = os.path.join(ROOT, pfile)
         pj = None
@@ -311,7 +322,7 @@ def main():
                 pj = json.load(f)
         if pj and pj.get("workload") == cfg["name"] and world == 1 and "path_kernel" in pj and timing["batches"] and not args.wide:
             d = pj["path_kernel"]
-            live_s = avg_ms * 1e-3
+            live_s = rate_ms * 1e-3
             roof["counter_pass"] = {"file": pfile, "launch_ms_in_pass": d["trace_mean_ms"],
                                     "clock_ghz_in_pass": d["clock_ghz"],
                                     "kernel_source_matches": pj.get("source_hash") == kernel_source_hash(),
@@ -335,7 +346,7 @@ def main():
             if "lane_stats" in d:
                 roof["inner_lanes_per_step"] = d["lane_stats"]["inner_lanes_per_step"]
             other = {}
-            scale = d["trace_mean_ms"] / avg_ms
+            scale = d["trace_mean_ms"] / rate_ms
             if "ta_busy_frac" in d:
                 other["address_unit_busy"] = {"frac": min(1.0, d["ta_busy_frac"] * scale),
                                               "note": "TA_TA_BUSY / (256 x cycles): a busy share, not a throughput"}
@@ -396,7 +407,7 @@ def main():
             executed = cnt["path_kernel_ray_casts"] + pixels_local * launches_per_step
             roof.update({
                 "algorithmic_bytes_per_launch": per_launch,
-                "algorithmic_GBps": per_launch / (avg_ms * 1e-3) / 1e9,
+                "algorithmic_GBps": per_launch / (rate_ms * 1e-3) / 1e9,
                 "algorithmic_bytes_note": "reference layout and visit order: 36 B per box test + 36 B per triangle test + "
                                           "48 B per sphere per cast; served almost entirely by the vector L1s, so this is "
                                           "not a traffic figure",

@@ -58,7 +58,10 @@ def _check_roofline(d, cfg_no):
     t = 0.0 if hi == lo else (x - rows[lo][0]) / (rows[hi][0] - rows[lo][0])
     peak = 1.0 / ((1 - t) / rows[lo][1] + t / rows[hi][1])
     assert abs(r["peak"] - peak) < 1e-6 * peak
-    achieved = pmc["vmem_read_instructions"] / (r["avg_launch_ms"] * 1e-3) / 1e9
+    # over the launch's own duration, or over the wall time per launch when consecutive launches overlap
+    assert r["rate_launch_ms"] == (r["wall_ms_per_launch"] if r["launches_overlap"] else r["avg_launch_ms"])
+    assert r["launches_overlap"] == (r["avg_launch_ms"] > r["wall_ms_per_launch"])
+    achieved = pmc["vmem_read_instructions"] / (r["rate_launch_ms"] * 1e-3) / 1e9
     assert abs(r["achieved"] - achieved) < 1e-6 * achieved
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["peak"] <= r["absolute_ceiling"]["peak"] * 1.001          # the tighter of the two ceilings is the one quoted

@@ -99,7 +99,10 @@ typedef struct pt_counters {
 } pt_counters;
 
 /* HIP-event timing of the kernels launched by the render calls since the last
- * pt_reset_timing (events are recorded on the context's stream). */
+ * pt_reset_timing (events are recorded around every kernel on the stream it runs on).  Consecutive
+ * batches of frames run on two streams and overlap, so the sums below can exceed the wall time; the
+ * primary-ray kernel runs only when camera, scene or pixel shard have changed since the batch slot's
+ * last use. */
 typedef struct pt_timing {
     uint64_t frames;           /* frames rendered */
     uint64_t batches;          /* launches of each kernel (frames are rendered in batches) */
@@ -159,14 +162,19 @@ int pt_rebuild_scene(pt_ctx *ctx, const float *triangles, uint32_t triangle_coun
 
 /* Replaces the camera position / rotation buffers, bindings 3 and 4, written
  * every frame by State::render (src/main.rs:455-464).  Rotation in degrees,
- * applied as in rotate_vector (shader.wgsl:327-348). */
+ * applied as in rotate_vector (shader.wgsl:327-348).  Takes effect for the frames enqueued afterwards;
+ * frames already enqueued keep the pose they were enqueued with.  A pose equal to the current one bit for
+ * bit changes nothing (the primary rays' results are kept across calls while the pose stands). */
 int pt_set_camera(pt_ctx *ctx, const float position[3], const float rotation_degrees[3]);
 
 /* Replaces the frame_count upload + the two draws + `frame_count += 1` of
  * State::render (src/main.rs:448-452, 498-510), n_frames times: frame f uses
  * frame_count = first_frame_count + f and folds its per-pixel mean into the
  * accumulation buffer with weight 1/(frame_count+1) (shader.wgsl:104-106), so
- * frame_count 0 overwrites the buffer.  Asynchronous on the context's stream. */
+ * frame_count 0 overwrites the buffer.  Asynchronous: the call enqueues and returns (pt_synchronize,
+ * pt_wait_in_flight, pt_read_accum wait).  Batches of frames of consecutive calls alternate between two
+ * streams of the context, so that one starts while the one before it drains; the frames are folded into
+ * the accumulation buffer in call and frame order all the same. */
 int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames);
 
 /* pt_render_frames for callers that cannot allocate device memory (code under HIP graph capture,
@@ -174,8 +182,8 @@ int pt_render_frames(pt_ctx *ctx, uint32_t first_frame_count, uint32_t n_frames)
  * result as pt_render_frames, bit for bit, but the per-batch working state (hit list, control words,
  * per-pixel tables, sample buffer) lives in a static device array of pt_static_scratch_bytes()
  * (64 MiB) that every GPU the library runs on holds until the process ends, and the call itself
- * calls no hipMalloc / hipFree / hipEventCreate: it only enqueues memsets and kernels on the
- * context's stream.  Scene, camera and accumulation buffer are the context's, as in
+ * calls no hipMalloc / hipFree / hipEventCreate: it only enqueues memsets, kernels and waits on events created by pt_create, on the
+ * context's first stream.  Scene, camera and accumulation buffer are the context's, as in
  * pt_render_frames.  Needs 8448 + 36 * width * height + 16 * roundup64(width * height) *
  * rays_per_pixel bytes for a one-frame batch (more frames per batch are used when they fit);
  * PT_EINVAL with the two byte counts in the message when that exceeds the array.  The kernels are not

@@ -105,6 +105,7 @@ struct pt_ctx {
     unsigned long long view_epoch = 1; /* bumped by whatever changes the primary pass's results */
     bool pipeline = true;              /* PT_PIPELINE=0: every batch on slot 0 */
     bool adapt_grid = true;            /* PT_ADAPT_GRID=0: the path kernel always gets its full grid */
+    bool timing_events = true;         /* PT_NO_TIMING=1: no HIP events around the kernels (pt_get_timing then reports no kernel time) */
     size_t pipeline_bytes = (size_t)16 << 30;  /* largest sample buffer a pipelined batch may need (PT_PIPELINE_MB) */
     size_t spill_words = 0;            /* size the scene asks of BatchSlot::d_spill */
     unsigned long long known_hits_epoch = 0;   /* view_epoch for which known_hits is the primary pass's hit count */
@@ -515,6 +516,7 @@ int drain_events(pt_ctx *c) {
 struct Timed {
     pt_ctx *c; hipStream_t st; EventPair ep; bool ok;
     Timed(pt_ctx *ctx, hipStream_t stream, int kind) : c(ctx), st(stream), ok(false) {
+        if (!c->timing_events) return;
         if (get_event_pair(c, ep) == PT_OK) { ep.kind = kind; ok = hipEventRecord(ep.start, st) == hipSuccess; }
     }
     void done() { if (ok) { (void)hipEventRecord(ep.stop, st); c->pending.push_back(ep); } }
@@ -893,6 +895,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     if (const char *e = getenv("PT_STARVE_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->starve_min = (uint32_t)v; }
     if (const char *e = getenv("PT_PIPELINE")) c->pipeline = atoi(e) != 0;
     if (const char *e = getenv("PT_ADAPT_GRID")) c->adapt_grid = atoi(e) != 0;
+    if (const char *e = getenv("PT_NO_TIMING")) c->timing_events = atoi(e) == 0;
     if (const char *e = getenv("PT_PIPELINE_MB")) { long v = atol(e); if (v >= 0) c->pipeline_bytes = (size_t)v << 20; }
     if (const char *e = getenv("PT_LEAF_SHIFT")) { int v = atoi(e); if (v >= 0 && v <= 6) c->leaf_shift = (uint32_t)v; }
     if (const char *e = getenv("PT_LEAF_MIN")) { int v = atoi(e); if (v >= 1 && v <= 64) c->leaf_min = (uint32_t)v; }

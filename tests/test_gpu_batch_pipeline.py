@@ -244,3 +244,26 @@ def test_overlapping_calls_give_the_same_bits_every_time(pkg, scenes, oracle_sha
     assert len(sums) == 1
     want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 7)
     assert np.array_equal(bits(img[..., :3]), bits(want[..., :3]))
+
+
+@pytest.mark.parametrize("distance", [1500.0, 6000.0, 1.0e5], ids=["some-hits", "few-hits", "no-hits"])
+def test_fewer_hit_pixels_than_queue_parts(pkg, scenes, oracle_shared, distance):
+    """The camera far from the mesh: a handful of hit pixels (or none), so most of the queue's parts are empty and
+    the waves that start on them must find the others; three calls so that the kept primary pass and the small grid
+    are used too."""
+    cfg, tris, bvh, spheres = _setup(scenes)
+    rot = list(map(float, cfg["camera_rotation"]))
+    pos = [float(cfg["camera_position"][0]), float(cfg["camera_position"][1]), distance]
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        ids, _ = r.primary_hits()
+        r.render_frames(0, 2)
+        r.synchronize()
+        r.render_frames(2, 3)
+        r.render_frames(5, 1)
+        got = r.read_accum(4)
+    hits = int((ids != np.iinfo(np.int32).min).sum())
+    assert hits < 2000 if distance < 1e5 else hits == 0 or hits < 64
+    want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 6)
+    assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))

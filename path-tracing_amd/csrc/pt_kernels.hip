@@ -1273,7 +1273,10 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_m
  * pixel; every pixel is written by exactly one thread.
  * The kernel may share the GPU with the path kernel of the NEXT batch (enqueued on another stream), whose waves
  * would leave it one issue slot in seven: it raises its own priority, because the batch after that one waits for it.
- * It also leaves the queue heads at zero for the next path kernel that uses these control words. */
+ * It also leaves the queue heads at zero for the next path kernel that uses these control words.  Beside a FULL grid of
+ * the path kernel (six waves of 80 registers per SIMD) no wave of any other kernel becomes resident, not even one of 8
+ * registers (tools/corun_probe.py): this kernel then runs when that grid begins to drain, which is when the batch that waits
+ * for it can start anyway.  Beside the smaller grids that short batches get it runs at once. */
 __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1286,7 +1289,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
         const float4 *s = P.samples + (size_t)sample_slot(t, 0u, per_hit);
         for (uint32_t b = 0; b < P.batch_frames; b++) {
             V3 sum = mk(0.0f, 0.0f, 0.0f);
-#pragma unroll 4
+#pragma unroll 2
             for (uint32_t k = 0; k < rpp; k++) {          /* shader.wgsl:99-101, in sample order */
                 float4 v = s[(size_t)(b * rpp + k) * 64u];
                 sum = sum + mk(v.x, v.y, v.z);

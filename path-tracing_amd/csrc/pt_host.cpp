@@ -794,8 +794,8 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
          * they are worth then.  A batch that will share the GPU with the batch before it (that one is still
          * running on the other stream) takes fewer blocks per CU the shorter it is: two grids side by side pass
          * the CUs to each other smoothly, and the shorter a kernel, the larger the part of its life its drain is.
-         * Measured, 1080p: 16 M paths 2.73 / 2.57 / 2.50 / 2.45 ms per render with 6 / 5 / 4 / 3 blocks per CU,
-         * 33 M paths 9.74 / 9.64 / 9.80 / 9.88, 271 M paths 43.05 / 43.21 / 43.82 / 44.15. */
+         * Measured, 1080p, two renders in flight, ms per render with 6 / 4 / 3 / 2 blocks per CU: 16 M paths 2.33 / 2.30 /
+         * 2.22 / 2.54, 33 M paths 9.39 / 9.10 / 9.22 / -; 271 M paths (6 / 5 / 4 / 3) 43.05 / 43.21 / 43.82 / 44.15. */
         int grid_cap = 0;
         if (c->adapt_grid && c->known_hits_epoch == c->view_epoch) {
             const unsigned long long paths = (unsigned long long)c->known_hits * rpp * batch;
@@ -806,7 +806,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
                 if (grid_cap < 1) grid_cap = 1;
             } else if (s != c->last_slot && c->slot[c->last_slot].stream && hipStreamQuery(c->slot[c->last_slot].stream) == hipErrorNotReady) {
                 (void)hipGetLastError();
-                grid_cap = paths < 64u * full ? 4 : paths < 256u * full ? 5 : 0;
+                grid_cap = paths < 64u * full ? 3 : paths < 256u * full ? 4 : 0;
             }
         }
         b.queue_clean = false;

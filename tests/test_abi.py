@@ -108,7 +108,7 @@ def _rust_blocks():
 
 
 def test_integration_document_params_struct_matches_the_abi(pkg):
-    """The Rust FFI stub a maintainer would paste from INTEGRATION.md: its `pt_params` must have the header's fields,
+    """The Rust FFI stub a maintainer would paste from the integration guide: its `pt_params` must have the header's fields,
     in the header's order and with the header's types, or the library reads a struct of another size."""
     rust = _rust_blocks()
     m = re.search(r"#\[repr\(C\)\]\s*pub struct pt_params\s*\{(.*?)\}", rust, flags=re.S)

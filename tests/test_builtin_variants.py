@@ -7,7 +7,7 @@ plus one that lets the C compiler fuse every a * b + c as GPU shader compilers d
   - checks, where the reference shader is on the machine, that each variant build computes what the shader's text
     computes under the same choice (interpreter with `choices`), bit for bit, on a few casts and paths;
   - counts what changes against the pinned oracle on the five benchmark scenes (tests/golden/builtin_variants.json is
-    the committed table, DESIGN.md quotes it) and bounds it: the primary id moves on at most one pixel in 57 600,
+    the committed table) and bounds it: the primary id moves on at most one pixel in 57 600,
     at most one pixel in a thousand moves by more than 2e-3 relative.
 """
 import json

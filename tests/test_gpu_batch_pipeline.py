@@ -267,3 +267,16 @@ def test_fewer_hit_pixels_than_queue_parts(pkg, scenes, oracle_shared, distance)
     assert hits < 2000 if distance < 1e5 else hits == 0 or hits < 64
     want = _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, 6)
     assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+
+
+def test_random_call_sequences_with_and_without_the_batch_slots():
+    """tools/fuzz_calls.py: 800 random API calls (renders, sums, camera moves, resets, scales, waits, static renders,
+    uploads, refits, shard changes) applied to a context with the two batch slots and to one with a single stream and
+    the full grid; the accumulation buffers are compared after every read."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_calls.py"), "11", "800"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "all equal" in res.stdout

@@ -59,6 +59,32 @@ PTD_FN float pt_div_by_reciprocal(float a, float b, float y) {
     return PTD_FMA(r, y, q);
 }
 
+/*
+ * The same quotient with one operation less, from a reciprocal kept in two parts.
+ *
+ *     yl = RN((1 - b*y) * y)      with 1 - b*y exact in one FMA: y + yl = (1/b)(1 + e2), |e2| <= 2^-47
+ *     t  = RN(a*yl)               q0 = RN(a*y + t)   (one FMA)
+ *     r  = a - b*q0   (exact)     q  = RN(q0 + r*y)
+ *
+ * Why q == RN(a/b) (same scaling as above): a*y + t = x(1 + h) with |h| <= 2^-47 + 2^-48 (the error of y + yl plus
+ * the rounding of t, |t| <= |x|*2^-24*(1 + 2^-23)), so |x - q0| <= (1/2 + 2^-22) ulp; r is then a multiple of
+ * ulp(b)*ulp(q0) below 2^24 such units, hence exact, and q = RN(x + (x - q0)*e1) with the same bound on the
+ * perturbation as in the five-operation form: b*2^-49*2^e*(1 + 2^-21), below the distance 2^-47*2^e/b of a
+ * quotient to the nearest rounding boundary whenever b*b*(1 + 2^-21) < 4.  t must not lose more than 2^-48 |x| to
+ * underflow: |a| >= 2^-80 (then |x| >= 2^-100 and 2^-150 <= 2^-48 |x|), which pt_div_tame_coordinate grants.
+ * Checked by the same brute force (tests/native/div_check.c).
+ */
+PTD_FN float pt_reciprocal_low(float b, float y) {
+    float e = PTD_FMA(-b, y, 1.0f);
+    return e * y;
+}
+PTD_FN float pt_div_by_reciprocal2(float a, float b, float y, float yl) {
+    float t = a * yl;
+    float q = PTD_FMA(a, y, t);
+    float r = PTD_FMA(-b, q, a);
+    return PTD_FMA(r, y, q);
+}
+
 /* denominator: exponent in [-20, 20], significand below 0x7fff00 */
 PTD_FN int pt_div_safe_denominator(float b) {
     uint32_t u = ptd_bits(b);
@@ -67,12 +93,13 @@ PTD_FN int pt_div_safe_denominator(float b) {
 }
 
 /* A coordinate c (ray origin component or box bound) is "tame" when it is 0 or
- * 2^-76 <= |c| <= 2^90.  The difference of two tame coordinates is 0 or at least
- * 2^-100 in magnitude (it is a multiple of the smaller operand's ulp, 2^-99 at
- * worst) and below 2^91, which is what pt_div_by_reciprocal needs. */
+ * 2^-56 <= |c| <= 2^90.  The difference of two tame coordinates is 0 or at least
+ * 2^-80 in magnitude (it is a multiple of the smaller operand's ulp, 2^-79 at
+ * worst) and below 2^91, which is what pt_div_by_reciprocal2 needs (pt_div_by_reciprocal
+ * makes do with 2^-100). */
 PTD_FN int pt_div_tame_coordinate(float c) {
     uint32_t u = ptd_bits(c) & 0x7fffffffu;
-    return u == 0u || (u >= ((127u - 76u) << 23) && u <= ((127u + 90u) << 23));
+    return u == 0u || (u >= ((127u - 56u) << 23) && u <= ((127u + 90u) << 23));
 }
 
 #endif /* PT_EXACT_DIV_H */

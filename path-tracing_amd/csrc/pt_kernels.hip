@@ -134,8 +134,8 @@ __device__ __forceinline__ void primary_ray(const PTKernelParams &P, uint32_t px
  * The two boxes ride in the two halves of packed-f32 instructions (v_pk_add_f32,
  * v_pk_mul_f32, v_pk_fma_f32), which is why the record stores them interleaved.
  * FAST selects how the quotients are formed: the plain correctly rounded
- * division, or pt_div_by_reciprocal's multiply + four FMAs with y = 1/d
- * precomputed per ray (same bits).  The caller picks FAST only for rays and
+ * division, or pt_div_by_reciprocal2's multiply + three FMAs with y = 1/d and its
+ * low part precomputed per ray (same bits).  The caller picks FAST only for rays and
  * scenes that satisfy the predicates in pt_exact_div.h. */
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u4_t __attribute__((ext_vector_type(4)));
@@ -145,15 +145,15 @@ __device__ __forceinline__ float4 u4_as_f4(u4_t w) { return make_float4(__uint_a
 __device__ __forceinline__ u4_t f4_as_u4(float4 v) { u4_t w; w.x = __float_as_uint(v.x); w.y = __float_as_uint(v.y); w.z = __float_as_uint(v.z); w.w = __float_as_uint(v.w); return w; }
 
 template <bool FAST>
-__device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y) {
+__device__ __forceinline__ f2 div2(f2 n, f2 b, f2 y, f2 yl) {
     if (FAST) {
-        f2 q = n * y;
 #ifdef PT_ABL_APPROX_DIV    /* timing probe only: the uncorrected product (results are no longer the shader's) */
-        return q;
+        return n * y;
 #endif
+        /* pt_div_by_reciprocal2, two quotients at a time */
+        f2 t = n * yl;
+        f2 q = __builtin_elementwise_fma(n, y, t);
         f2 r = __builtin_elementwise_fma(-b, q, n);
-        q = __builtin_elementwise_fma(r, y, q);
-        r = __builtin_elementwise_fma(-b, q, n);
         return __builtin_elementwise_fma(r, y, q);
     }
     return mk2(n.x / b.x, n.y / b.y);
@@ -184,19 +184,19 @@ __device__ __forceinline__ float box_result(float tminx, float tminy, float tmin
 
 /* The ray as the box test wants it: x and y ride together in packed instructions, z is
  * paired with itself (min plane and max plane of one box). */
-struct RayPk { f2 oxy, ozz, dxy, dzz, yxy, yzz; };
+struct RayPk { f2 oxy, ozz, dxy, dzz, yxy, yzz, ylxy, ylzz; };      /* y = 1/d, yl = pt_reciprocal_low(d, y) */
 
 /* q0 = (A.min.x, A.min.y, A.max.x, A.max.y)  q1 = (B.min.x, B.min.y, B.max.x, B.max.y)
  * q2 = (A.min.z, A.max.z, B.min.z, B.max.z) */
 struct Box2 { float near_a, far_a, near_b, far_b; };      /* t_near / t_far of the two children's slab tests */
 template <bool FAST>
 __device__ __forceinline__ Box2 ray_box2_nf(const RayPk &R, float4 q0, float4 q1, float4 q2) {
-    f2 a_min = div2<FAST>(mk2(q0.x, q0.y) - R.oxy, R.dxy, R.yxy);
-    f2 a_max = div2<FAST>(mk2(q0.z, q0.w) - R.oxy, R.dxy, R.yxy);
-    f2 b_min = div2<FAST>(mk2(q1.x, q1.y) - R.oxy, R.dxy, R.yxy);
-    f2 b_max = div2<FAST>(mk2(q1.z, q1.w) - R.oxy, R.dxy, R.yxy);
-    f2 a_z = div2<FAST>(mk2(q2.x, q2.y) - R.ozz, R.dzz, R.yzz);
-    f2 b_z = div2<FAST>(mk2(q2.z, q2.w) - R.ozz, R.dzz, R.yzz);
+    f2 a_min = div2<FAST>(mk2(q0.x, q0.y) - R.oxy, R.dxy, R.yxy, R.ylxy);
+    f2 a_max = div2<FAST>(mk2(q0.z, q0.w) - R.oxy, R.dxy, R.yxy, R.ylxy);
+    f2 b_min = div2<FAST>(mk2(q1.x, q1.y) - R.oxy, R.dxy, R.yxy, R.ylxy);
+    f2 b_max = div2<FAST>(mk2(q1.z, q1.w) - R.oxy, R.dxy, R.yxy, R.ylxy);
+    f2 a_z = div2<FAST>(mk2(q2.x, q2.y) - R.ozz, R.dzz, R.yzz, R.ylzz);
+    f2 b_z = div2<FAST>(mk2(q2.z, q2.w) - R.ozz, R.dzz, R.yzz, R.ylzz);
     Box2 r;
     box_near_far(a_min.x, a_min.y, a_z.x, a_max.x, a_max.y, a_z.y, r.near_a, r.far_a);
     box_near_far(b_min.x, b_min.y, b_z.x, b_max.x, b_max.y, b_z.y, r.near_b, r.far_b);
@@ -275,11 +275,17 @@ struct Trav {
     RayPk R;           /* origin, direction and 1/direction in the layout ray_box2 wants */
 };
 
+/* the low parts of the reciprocals (pt_reciprocal_low), from d and y */
+__device__ __forceinline__ void raypk_low(RayPk &R) {
+    R.ylxy = __builtin_elementwise_fma(-R.dxy, R.yxy, mk2(1.0f, 1.0f)) * R.yxy;
+    R.ylzz = __builtin_elementwise_fma(-R.dzz, R.yzz, mk2(1.0f, 1.0f)) * R.yzz;
+}
 __device__ __forceinline__ void raypk_set(RayPk &R, V3 o, V3 d) {
     R.oxy = mk2(o.x, o.y); R.ozz = mk2(o.z, o.z);
     R.dxy = mk2(d.x, d.y); R.dzz = mk2(d.z, d.z);
     float iz = 1.0f / d.z;
     R.yxy = mk2(1.0f / d.x, 1.0f / d.y); R.yzz = mk2(iz, iz);
+    raypk_low(R);
 }
 
 /* origin and direction only (a ray that is shaded, not cast) */
@@ -1109,6 +1115,7 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_m
                 T.R.oxy = mk2(park_o.x, park_o.y); T.R.ozz = mk2(park_o.z, park_o.z);
                 T.R.dxy = mk2(park_d.x, park_d.y); T.R.dzz = mk2(park_d.z, park_d.z);
                 T.R.yxy = mk2(park_y.x, park_y.y); T.R.yzz = mk2(park_y.z, park_y.z);
+                raypk_low(T.R);
                 safe = park_safe;
                 trav_begin(P, stack_bottom(M), T);
                 if (act1) ready1 = false; else ready0 = false;

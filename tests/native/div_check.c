@@ -1,4 +1,4 @@
-/* Brute-force check that pt_div_by_reciprocal(a, b, 1/b) == a / b bit for bit for every
+/* Brute-force check that pt_div_by_reciprocal(a, b, 1/b) and pt_div_by_reciprocal2(a, b, 1/b, low part) == a / b bit for bit for every
  * (a, b) the kernels may feed it (predicates of csrc/pt_exact_div.h).  Built and run by
  * tests/test_exact_division.py.  Prints "<cases> <mismatches>". */
 #include <math.h>
@@ -26,7 +26,7 @@ int main(int argc, char **argv) {
         for (long i = 0; i < n_random; i++) {
             uint64_t r1 = rng(&s), r2 = rng(&s);
             uint32_t mb = r1 & 0x7fffff, ma = r2 & 0x7fffff;
-            int eb = (int)((r1 >> 23) % 41) - 20, ea = (int)((r2 >> 23) % 201) - 100;
+            int eb = (int)((r1 >> 23) % 41) - 20, ea = (int)((r2 >> 23) % 181) - 80;      /* |a| in [2^-80, 2^101) */
             if ((i & 15) == 0) mb = 0x7ffeff - (uint32_t)((r1 >> 41) & 0xff);   /* just below the excluded top */
             if ((i & 15) == 1) mb = (uint32_t)((r1 >> 41) & 0xff);
             if ((i & 15) == 2) ma = ((r2 >> 41) & 1) ? 0x7fffff : 0;
@@ -35,13 +35,15 @@ int main(int argc, char **argv) {
             if ((i & 1023) == 3) a = 0.0f;
             if (!pt_div_safe_denominator(b)) continue;
             float y = 1.0f / b, want = a / b, got = pt_div_by_reciprocal(a, b, y);
+            float got2 = pt_div_by_reciprocal2(a, b, y, pt_reciprocal_low(b, y));
             total++;
             if (asu(got) != asu(want) && !(got == 0.0f && want == 0.0f)) bad++;
+            if (asu(got2) != asu(want) && !(got2 == 0.0f && want == 0.0f)) bad++;
         }
         /* adversarial: for every significand of b, quotients next to a rounding boundary */
 #pragma omp for schedule(dynamic, 4096)
         for (uint32_t mb = 0; mb < 0x7fff00u; mb += 1) {
-            float b = asf(0x3f800000u | mb), y = 1.0f / b;
+            float b = asf(0x3f800000u | mb), y = 1.0f / b, yl = pt_reciprocal_low(b, y);
             uint64_t t = 0xD1B54A32D192ED03ull ^ ((uint64_t)mb * 0x9E3779B97F4A7C15ull);
             for (int k = 0; k < 8; k++) {
                 uint32_t mq = (uint32_t)(rng(&t) & 0x7fffff);
@@ -49,9 +51,10 @@ int main(int argc, char **argv) {
                 float a0 = (float)(qmid * (double)b);
                 for (int dl = -1; dl <= 1; dl++) {
                     float a = asf(asu(a0) + (uint32_t)dl);
-                    float want = a / b, got = pt_div_by_reciprocal(a, b, y);
+                    float want = a / b, got = pt_div_by_reciprocal(a, b, y), got2 = pt_div_by_reciprocal2(a, b, y, yl);
                     total++;
                     if (asu(got) != asu(want)) bad++;
+                    if (asu(got2) != asu(want)) bad++;
                 }
             }
         }

@@ -6,7 +6,9 @@
  * backend is bit-exactness with that IEEE division.  A ray tests ~150 boxes per
  * cast against the SAME three denominators, so the reciprocal y = RN(1/b) is
  * computed once per ray (one true division) and each quotient is then formed
- * with one multiply and four fused multiply-adds:
+ * with one multiply and four fused multiply-adds (pt_div_by_reciprocal; the kernels
+ * use the shorter pt_div_by_reciprocal2 further down, which needs a second word per
+ * reciprocal):
  *
  *     q0 = RN(a*y)            r0 = a - b*q0   (exact in an FMA)
  *     q1 = RN(q0 + r0*y)      r1 = a - b*q1   (exact)

@@ -107,7 +107,7 @@ struct PTKernelParams {
     float4 *pathbuf;               /* two-paths-per-lane state: pt_pathbuf_bytes() */
     uint32_t pathbuf_bytes;
     uint32_t quad_fetch;           /* path kernel: the four lanes of a quad fetch each other's inner records (one cache line per gather and quad) */
-    uint32_t fast_div;             /* every box bound is 0 or in [2^-76, 2^90]: ray_box may use reciprocals */
+    uint32_t fast_div;             /* every box bound is 0 or in [2^-56, 2^90]: ray_box may use reciprocals */
     const PTInnerRecord *inner;
     uint32_t tris_bytes;           /* size of the triangle-record array (at most 2^24 x 48 bytes) */
     uint32_t inner_bytes;          /* size of the inner-record array (below 2^32: the upload refuses 2^26 or more inner records) */

@@ -97,7 +97,7 @@ def test_refit_switches_the_division_form_with_the_bounds(pkg, oracle_shared, sc
     """Bounds outside the range of the reciprocal slab test (pt_exact_div.h) after a refit: the plain divider
     takes over and results stay the oracle's."""
     tris, bvh = scenes.mesh("teapot")
-    huge = (tris.astype(np.float64) * 1e-30).astype(F)      # bounds around 1e-28 < 2^-76
+    huge = (tris.astype(np.float64) * 1e-30).astype(F)      # bounds around 1e-28 < 2^-56
     bvh_h = refit_nodes(huge, bvh)
     W, H = 64, 36
     p = pkg.default_params(width=W, height=H, rays_per_pixel=1, max_bounce_count=1, flags=pkg.PT_FLAG_EXACT_MATH)

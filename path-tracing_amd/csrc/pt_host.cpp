@@ -608,7 +608,7 @@ int static_work_buffers(pt_ctx *c, uint32_t n_frames, WorkBuffers &wb) {
                     std::to_string(off + per_frame) + " bytes of scratch, the static array holds " +
                     std::to_string((size_t)PT_STATIC_SCRATCH_BYTES) + " (use pt_render_frames)");
     size_t nb = (PT_STATIC_SCRATCH_BYTES - off) / per_frame;
-    if (nb > 0xffffffffull / (slots_per_frame + 512u * c->params.rays_per_pixel))       /* the queue arithmetic rounds up to eight parts of whole groups */
+    if (nb > 0xffffffffull / (slots_per_frame + 512u * c->params.rays_per_pixel))       /* the queue arithmetic rounds the hit pixels up to whole parts (fewer than 512 pixels more) */
         nb = 0xffffffffull / (slots_per_frame + 512u * c->params.rays_per_pixel);
     if (nb > 64) nb = 64;
     if (nb > n_frames) nb = n_frames ? n_frames : 1;
@@ -927,8 +927,8 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
         if (const char *ev = getenv("PT_SAMPLE_BUDGET_MB")) { long v = atol(ev); if (v > 0) budget = (size_t)v << 20; }
         c->sample_budget = budget;
         if (const char *ev = getenv("PT_SMALL_SAMPLE_MB")) { long v = atol(ev); if (v >= 0) c->small_sample_bytes = (size_t)v << 20; }
-        /* hit pixels are stored in interleaved groups of 64; the path kernel's queue arithmetic (eight parts of
-         * whole groups) goes up to (hit pixels + 8 * 64) * frames * rays_per_pixel */
+        /* hit pixels are stored in interleaved groups of 64; the path kernel's queue arithmetic (PT_QUEUE_PARTS equal
+         * parts of whole pixels) stays below (hit pixels + 512) * frames * rays_per_pixel */
         const size_t slots_per_frame = ((npix + 63) / 64 * 64 + 512) * params->rays_per_pixel;
         size_t nb = 0xffffffffull / slots_per_frame;
         if (nb < 1) { fail(nullptr, PT_EINVAL, "width * height * rays_per_pixel does not fit the 32-bit sample numbering"); pt_destroy(c); return PT_EINVAL; }
@@ -1055,7 +1055,9 @@ int pt_rebuild_scene(pt_ctx *c, const float *triangles, uint32_t triangle_count,
         pt_resident_tree_free(t);
         return fail(c, PT_EINVAL, "BVH depth " + std::to_string(t.depth) + " exceeds the supported traversal stack");
     }
-    hipError_t e = sync_all(c);
+    /* the builder has put the caller's device back: what follows allocates on the context's */
+    hipError_t e = hipSetDevice(c->device);
+    if (e == hipSuccess) e = sync_all(c);
     uint32_t *spill = nullptr;
     float *sph = c->d_spheres;
     const size_t spill_words = (size_t)pt_spill_entries((uint32_t)need) * pt_lane_stride(c->num_cus);

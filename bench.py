@@ -29,6 +29,8 @@ Extra objects in the line:
                  box test, 36 B per triangle test, 48 B per sphere per cast, counted by an
                  instrumented run of the same launches) are reported as `algorithmic_over_actual`
                  against the bytes that really left the L2s.
+  exact_math   - the timed region once more under PT_FLAG_EXACT_MATH, the mode whose whole images equal
+                 the CPU restatement bit for bit (N = 1 only), with a one-frame bit comparison.
   cpu_baseline - the CPU oracle (oracle/, a C restatement of the reference shader;
                  the reference itself cannot run here) on a bounded sample of the
                  same workload, rank 0 at N = 1 only.
@@ -142,6 +144,7 @@ def main():
                     help="PT_FLAG_WIDE_BVH: four-wide tree (not the reference's visit order; reported under its own workload name)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting pass")
+    ap.add_argument("--no-exact", action="store_true", help="skip the second timed region under PT_FLAG_EXACT_MATH")
     args = ap.parse_args()
     if args.wide:
         args.no_count = True          # the work counters follow the reference's binary walk
@@ -453,6 +456,41 @@ def main():
                                        "rmse_over_mean": float(np.sqrt(np.mean((gimg.astype(np.float64) - acc[..., :3]) ** 2))
                                                                / acc[..., :3].mean()),
                                        "mean_rel_err_of_image_mean": float(abs(gimg.mean() - acc[..., :3].mean()) / acc[..., :3].mean())}
+
+    # ---- the same steps in the mode whose images equal the CPU restatement bit for bit (rank 0, N = 1 only) ----
+    if rank == 0 and world == 1 and not args.wide and not args.no_exact:
+        rx = make_renderer(pkg.PT_FLAG_EXACT_MATH)
+        for _ in range(max(1, args.warmup)):
+            rx.render_frames(0, n_frames)
+        rx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            rx.render_frames(0, n_frames)
+        rx.synchronize()
+        ex_s = time.perf_counter() - t0
+        ex_value = samples_per_step * args.steps / ex_s / 1e6
+        result["exact_math"] = {
+            "value": ex_value, "unit": "Msamples/s", "ms_per_step": ex_s / args.steps * 1e3,
+            "relative_to_value": ex_value / result["value"],
+            "note": "the same timed region under PT_FLAG_EXACT_MATH (log / cos / pow of the shading code from IEEE-only "
+                    "polynomials instead of v_log / v_cos / v_exp): every pixel of the image then equals the CPU restatement "
+                    "bit for bit; `value` above is the default mode, whose hit decisions are the same and whose radiance is "
+                    "within the tolerance of parity_spot_check",
+        }
+        if not args.no_cpu_baseline:
+            om = entry.load_oracle_module()
+            ox = om.Oracle(shared_math=True)
+            cores, _ = host_cores()
+            op = ox.default_params(width=W, height=H, rays_per_pixel=rpp, max_bounce_count=cfg["max_bounce_count"])
+            acc = np.zeros((H, W, 4), np.float32)
+            ox.render_frames(op, ox.scene(spheres, tris, bvh), cfg["camera_position"], cfg["camera_rotation"], 0, 1,
+                             accum=acc, nthreads=cores)
+            rx.render_frames(0, 1)
+            gimg = rx.read_accum(4)[..., :3]
+            same = (gimg.view(np.uint32) == acc[..., :3].view(np.uint32)).all(axis=-1)
+            result["exact_math"]["bit_equal_spot_check"] = {"frames": 1, "pixels": int(same.size),
+                                                            "pixels_bit_equal": int(same.sum())}
+        rx.close()
 
     r.close()
     if rank == 0:

@@ -34,6 +34,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "Msamples/s" and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     assert d["parity_spot_check"]["pixels_within_2e-3_rel"] > 0.99
+    # the timed region once more in the mode whose images equal the CPU restatement: every pixel of the spot check
+    x = d["exact_math"]
+    assert x["unit"] == "Msamples/s" and x["value"] > 0 and x["ms_per_step"] > 0
+    assert abs(x["relative_to_value"] - x["value"] / d["value"]) < 1e-9
+    assert x["bit_equal_spot_check"]["pixels"] == 640 * 360 == x["bit_equal_spot_check"]["pixels_bit_equal"]
 
 
 def _ceiling_rows():

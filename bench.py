@@ -142,6 +142,8 @@ def main():
                          "(bit-identical image), or both one after the other (value = the frame split)")
     ap.add_argument("--wide", action="store_true",
                     help="PT_FLAG_WIDE_BVH: four-wide tree (not the reference's visit order; reported under its own workload name)")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="N > 1: quote the steps that wait for their kernels and their collective (default: steps in flight)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="skip the instrumented counting pass")
     ap.add_argument("--no-exact", action="store_true", help="skip the second timed region under PT_FLAG_EXACT_MATH")
@@ -150,6 +152,12 @@ def main():
         args.no_count = True          # the work counters follow the reference's binary walk
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
+
+    if os.environ.get("PT_BENCH_WATCHDOG_S"):
+        # a rank that has not finished by then prints the Python stack of every thread and exits (tests of the N > 1
+        # path set this: a hang of two ranks then names its place instead of running into the caller's time limit)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PT_BENCH_WATCHDOG_S"]), exit=True)
 
     import numpy as np
     import torch
@@ -205,16 +213,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_split(mode):
+    def run_split(mode, pipelined):
         """W warm-up steps, then K timed steps of one way to split the render; returns the time (maximum over ranks),
-        the library's event timing of this rank and, for N > 1, every rank's figures."""
+        the library's event timing of this rank and, for N > 1, every rank's figures.  pipelined (N > 1): the steps are
+        enqueued without a wait on the host, collectives included (ShardedRenderer.render_async), as the steps of the
+        single-GPU run are; otherwise every step waits for its kernels and then for its collective."""
         # the image ends on rank 0
         sharded = ShardedRenderer(r, rank, world, mode=mode, collective="reduce",
                                   force_collective=world == 1) if grouped else None
         phase = {"render_s": 0.0, "collective_s": 0.0}
 
         def step(timed=False):
-            if sharded is not None:
+            if sharded is not None and pipelined:
+                sharded.render_async(0, n_frames)
+            elif sharded is not None:
                 sharded.render(0, n_frames)
                 if timed:
                     for k in phase:
@@ -225,15 +237,20 @@ def main():
                 # region ends with a synchronisation.
                 r.render_frames(0, n_frames)
 
+        def drain():
+            if sharded is not None:
+                sharded.finish()
+            r.synchronize()
+
         for _ in range(args.warmup):
             step()
-        r.synchronize()
+        drain()
         r.reset_timing()
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step(timed=True)
-        r.synchronize()
+        drain()
         fence()
         elapsed = time.perf_counter() - t0
         timing = r.timing()
@@ -245,18 +262,25 @@ def main():
             mine = {"rank": rank, "path_ms_per_step": timing["path_ms"] / args.steps,
                     "primary_ms_per_step": timing["primary_ms"] / args.steps,
                     "resolve_ms_per_step": timing["resolve_ms"] / args.steps,
-                    "render_ms_per_step": phase["render_s"] / args.steps * 1e3,
-                    "collective_ms_per_step": phase["collective_s"] / args.steps * 1e3,
                     "frames_per_step": timing["frames"] / args.steps}
+            if not pipelined:      # the host sees the two phases of a step only when it waits between them
+                mine["render_ms_per_step"] = phase["render_s"] / args.steps * 1e3
+                mine["collective_ms_per_step"] = phase["collective_s"] / args.steps * 1e3
             per_rank = [None] * world
             dist.all_gather_object(per_rank, mine)
-        return elapsed, timing, per_rank
+        checksum = None
+        if sharded is not None and rank == 0:
+            checksum = float(sharded.image().double().sum().item())
+        return elapsed, timing, per_rank, checksum
 
     # the split `value` is quoted on comes first: frames (samples per pixel split over the GPUs) unless --shard pixels
     modes = ["single"] if not grouped else (["frames", "pixels"] if args.shard == "both" else [args.shard])
-    runs = {m: run_split(m) for m in modes}
+    # N > 1: every split is timed twice, with a wait after every step's kernels and collective (which shows the two
+    # phases) and with the steps in flight; `value` is the latter unless --sync-steps
+    runs_sync = {m: run_split(m, False) for m in modes} if grouped else {}
+    runs = runs_sync if grouped and args.sync_steps else {m: run_split(m, grouped) for m in modes}
     shard_mode = modes[0]
-    elapsed, timing, per_rank = runs[shard_mode]
+    elapsed, timing, per_rank, _ = runs[shard_mode]
     parallelism_of = {
         "single": "single GPU, running mean",
         "pixels": "8x8-pixel tiles sharded over %d GPUs, one RCCL sum reduce to rank 0 per step" % world,
@@ -288,13 +312,24 @@ def main():
             "kernel_launches_per_step": timing["batches"] / max(1, args.steps),
         }
         if grouped:
+            def split_entry(m):
+                e, _, pr, chk = runs[m]
+                es, _, prs, chks = runs_sync[m]
+                return {"value": samples_per_step * args.steps / e / 1e6, "ms_per_step": e / args.steps * 1e3,
+                        "parallelism": parallelism_of[m], "per_rank": pr,
+                        "collective_ms_per_step": max(p["collective_ms_per_step"] for p in prs),
+                        "synchronous": {"value": samples_per_step * args.steps / es / 1e6, "ms_per_step": es / args.steps * 1e3,
+                                        "per_rank": prs,
+                                        "note": "the same steps with a wait after every step's kernels and after its collective"},
+                        "image_checksum_equal": chk == chks}
+            result["step_protocol"] = ("synchronous: every step waits for its kernels, then for its collective" if args.sync_steps else
+                                       "steps in flight: render, copy to a staging tensor and asynchronous collective of every step are "
+                                       "enqueued without a wait on the host, as the steps of the single-GPU run are; the timed region "
+                                       "ends with a wait for all of them")
             result["per_rank"] = per_rank
-            result["collective_ms_per_step"] = max(p["collective_ms_per_step"] for p in per_rank)
-            result["splits"] = {m: {"value": samples_per_step * args.steps / e / 1e6, "ms_per_step": e / args.steps * 1e3,
-                                    "parallelism": parallelism_of[m], "per_rank": pr,
-                                    "collective_ms_per_step": max(p["collective_ms_per_step"] for p in pr)}
-                                for m, (e, _, pr) in runs.items()}
-            result["predicted_efficiency"] = dict(PREDICTED_EFFICIENCY, note="render time of one rank's share run alone on one "
+            result["splits"] = {m: split_entry(m) for m in modes}
+            result["collective_ms_per_step"] = result["splits"][shard_mode]["collective_ms_per_step"]
+            result["predicted_efficiency"] = dict(PREDICTED_EFFICIENCY, note="for steps that wait (splits.*.synchronous): render time of one rank's share run alone on one "
                                                   "GPU, without the collective (tools/shard_cost.py); no N > 1 run on "
                                                   "hardware has been compared with it yet")
 

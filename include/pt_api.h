@@ -230,6 +230,35 @@ int pt_reset_accum(pt_ctx *ctx);
 int pt_bind_accum(pt_ctx *ctx, void *device_ptr);
 void *pt_accum_device_ptr(pt_ctx *ctx);
 
+/* Stream-ordered hand-over of the accumulation buffer between the context and a HIP stream of the
+ * caller's (hip_stream is a hipStream_t; NULL is the default stream), without a wait on the host.  No
+ * reference counterpart: wgpu orders the accesses to a buffer within its one queue itself
+ * (src/main.rs:498-508); here a caller that copies or reduces the image on a stream of its own (a
+ * collective on the torch stream, a copy into a display surface) says where its work fits in.
+ *   pt_accum_release: work enqueued on hip_stream from now on runs after everything the context has
+ *                     enqueued so far that reads or writes the accumulation buffer.
+ *   pt_accum_acquire: whatever the context enqueues from now on that reads or writes the accumulation
+ *                     buffer (the frame folds of later render calls, pt_scale_accum, pt_reset_accum)
+ *                     runs after the work enqueued on hip_stream so far; path kernels of later render
+ *                     calls, which do not touch the buffer, start without waiting.  The calls that
+ *                     synchronise (pt_synchronize, pt_read_accum, ...) wait for that work too.
+ * A loop  render; release(s); <copy the image on s>; acquire(s)  keeps the next render's kernels
+ * running while the copy of this one is still to come. */
+int pt_accum_release(pt_ctx *ctx, void *hip_stream);
+int pt_accum_acquire(pt_ctx *ctx, void *hip_stream);
+
+/* A second output for the NEXT render call (pt_render_frames, pt_render_frames_sum, pt_render_frames_static), and for
+ * that call only: the kernel that folds the call's last frames into the accumulation buffer writes every pixel's value
+ * to device_ptr as well (width*height*4 floats of device memory on this context's GPU, 16-byte aligned, not the
+ * accumulation buffer itself), so a caller that hands each image on (to a collective, to a display) while the next
+ * render is already running needs no copy kernel and no clearing between renders.  Pixels of other ranks' shards
+ * (pt_set_pixel_shard) are written as zeros.  move != 0: the accumulation buffer is left holding ZEROS where the
+ * call folded frames, the image exists in device_ptr only; a pt_render_frames_sum call then starts the next sum
+ * from nothing without a pt_reset_accum in between.  A call of no frames writes nothing.  NULL withdraws the
+ * request.  The write is ordered like the frame folds (pt_accum_release / pt_accum_acquire apply to it).  No reference
+ * counterpart (the reference presents its one buffer, src/main.rs:466-508). */
+int pt_next_render_output(pt_ctx *ctx, void *device_ptr, uint32_t move);
+
 /* Debug / parity output with no reference counterpart (the shader's HitInfo,
  * shader.wgsl:7-16, has no primitive id): closest hit of every pixel's primary
  * ray.  prim_id = triangle index >= 0, -(1+sphere index) for spheres, INT32_MIN

@@ -68,7 +68,8 @@ API_SYMBOLS = [
     "pt_last_error", "pt_bvh_build", "pt_free", "pt_bvh_build_gpu", "pt_bvh_build_gpu_error", "pt_bvh_build_gpu_release_cache", "pt_refit_scene", "pt_rebuild_scene",
     "pt_stl_format", "pt_stl_format_file", "pt_stl_format_error",
     "pt_update_camera", "pt_host_rotate_vector", "pt_set_pixel_shard", "pt_probe_functions", "pt_probe_intersections", "pt_write_accum",
-    "pt_render_frames_static", "pt_static_scratch_bytes", "pt_wait_in_flight",
+    "pt_render_frames_static", "pt_static_scratch_bytes", "pt_wait_in_flight", "pt_accum_release", "pt_accum_acquire",
+    "pt_next_render_output",
 ]
 
 # key order of State::keys_pressed (main.rs:39)
@@ -130,6 +131,9 @@ def load_library():
     L.pt_primary_hits.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
     L.pt_synchronize.argtypes = [C.c_void_p]
     L.pt_wait_in_flight.argtypes = [C.c_void_p, C.c_uint32]
+    L.pt_accum_release.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_accum_acquire.argtypes = [C.c_void_p, C.c_void_p]
+    L.pt_next_render_output.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.pt_get_counters.argtypes = [C.c_void_p, C.POINTER(PtCounters)]
     L.pt_reset_counters.argtypes = [C.c_void_p]
     L.pt_get_debug_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -434,6 +438,22 @@ class Renderer:
 
     def bind_accum(self, device_ptr):
         self._check(self._L.pt_bind_accum(self._ctx, C.c_void_p(device_ptr)))
+
+    def accum_release(self, hip_stream):
+        """pt_accum_release: work enqueued on `hip_stream` (a hipStream_t handle as an integer, e.g.
+        torch.cuda.Stream.cuda_stream; 0 = the default stream) from now on runs after everything enqueued so far
+        that touches the accumulation buffer.  No wait on the host."""
+        self._check(self._L.pt_accum_release(self._ctx, C.c_void_p(int(hip_stream))))
+
+    def accum_acquire(self, hip_stream):
+        """pt_accum_acquire: later work of this context on the accumulation buffer runs after what `hip_stream` holds
+        now; path kernels of later renders start without waiting."""
+        self._check(self._L.pt_accum_acquire(self._ctx, C.c_void_p(int(hip_stream))))
+
+    def next_render_output(self, device_ptr, move=False):
+        """pt_next_render_output: the next render call also writes its image to `device_ptr` (an integer device
+        address, or None to withdraw); move=True leaves the accumulation buffer at zero instead."""
+        self._check(self._L.pt_next_render_output(self._ctx, C.c_void_p(device_ptr), 1 if move else 0))
 
     def accum_device_ptr(self):
         return self._L.pt_accum_device_ptr(self._ctx)

@@ -102,6 +102,10 @@ struct pt_ctx {
     unsigned long long batch_seq = 0;  /* batches enqueued so far */
     hipEvent_t batch_done[2] = {nullptr, nullptr};     /* recorded behind batch number n in batch_done[n & 1] (pt_wait_in_flight) */
     int accum_last = -1;               /* slot whose stream touched the accumulation buffer last (-1: none yet) */
+    hipEvent_t ext_done = nullptr;     /* pt_accum_acquire: recorded on the caller's stream behind its work on the buffer */
+    bool ext_pending = false;          /* ... and nothing of the context has waited for it yet */
+    float4 *next_out = nullptr;        /* pt_next_render_output: second output of the next render call (one call only) */
+    bool next_move = false;
     unsigned long long view_epoch = 1; /* bumped by whatever changes the primary pass's results */
     bool pipeline = true;              /* PT_PIPELINE=0: every batch on slot 0 */
     bool adapt_grid = true;            /* PT_ADAPT_GRID=0: the path kernel always gets its full grid */
@@ -435,6 +439,7 @@ void fill_kernel_params(const pt_ctx *c, const BatchSlot &bs, uint32_t frame_fir
     k.div_rpp = pt_fastdiv_make(p.rays_per_pixel);
     k.div_batch = pt_fastdiv_make(batch_frames);
     k.accum_mode = accum_mode;
+    k.mirror = nullptr; k.mirror_move = 0;
     k.shard_rank = c->shard_rank; k.shard_world = c->shard_world;
     k.width_f = (float)p.width; k.height_f = (float)p.height;
     /* vs_main, shader.wgsl:36-37,68-69.  fov is a const-expression of abstract
@@ -527,12 +532,19 @@ hipError_t sync_all(pt_ctx *c) {
     hipError_t e = hipSuccess;
     for (int s = 0; s < 2; s++)
         if (c->slot[s].stream) { hipError_t es = hipStreamSynchronize(c->slot[s].stream); if (e == hipSuccess) e = es; }
+    /* ... and for what the caller's stream did to the accumulation buffer before it handed it back */
+    if (c->ext_pending) { hipError_t es = hipEventSynchronize(c->ext_done); if (e == hipSuccess) e = es; c->ext_pending = false; }
     return e;
 }
 
 /* The accumulation buffer is written in a fixed order (a running mean is folded frame by frame).  Whatever touches
  * it on slot s's stream first waits for the last such operation of the other stream, and leaves its own mark. */
 hipError_t accum_wait(pt_ctx *c, int s) {
+    if (c->ext_pending) {       /* the buffer was lent to a stream of the caller's (pt_accum_acquire): its work comes first */
+        hipError_t e = hipStreamWaitEvent(c->slot[s].stream, c->ext_done, 0);
+        if (e != hipSuccess) return e;
+        c->ext_pending = false;
+    }
     if (c->accum_last < 0 || c->accum_last == s) return hipSuccess;
     return hipStreamWaitEvent(c->slot[s].stream, c->slot[c->accum_last].accum_done, 0);
 }
@@ -678,6 +690,10 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
     /* counting contexts run their primary pass exactly once per batch and share one set of counters; the two-paths
      * schedule shares one set of path buffers: neither is pipelined */
     bool may_pipeline = !wb && c->pipeline && !count && !(c->two_paths && c->d_pathbuf);
+    /* the second output asked for with pt_next_render_output belongs to this call, however it ends */
+    float4 *const second_out = c->next_out;
+    const bool second_move = c->next_move;
+    c->next_out = nullptr; c->next_move = false;
     /* Frames are rendered in batches: camera and scene are constant within the call, so the
      * primary rays (identical for every sample of every frame, shader.wgsl:80-101) are cast once
      * per batch; the path kernel then runs the bounces of ALL frames of the batch from one queue
@@ -728,6 +744,7 @@ int render_impl(pt_ctx *c, uint32_t first, uint32_t n_frames, uint32_t stride, u
         }
         PTKernelParams k;
         fill_kernel_params(c, b, first + done * stride, stride, batch, mode, k);
+        if (done + batch == n_frames) { k.mirror = second_out; k.mirror_move = second_move ? 1u : 0u; }     /* the batch that ends the call */
         if (wb) { k.ctrl = wb->ctrl; k.pixel_hit = wb->pixel_hit; k.pixel_const = wb->pixel_const; k.hits = wb->hits; k.samples = wb->samples; }
         if (cached) {
             /* only the queue heads start again (the last resolve kernel has seen to that, unless a call failed half
@@ -915,6 +932,7 @@ int pt_create(int device_ordinal, const pt_params *params, pt_ctx **out) {
     c->stream = c->slot[0].stream;
     for (hipEvent_t &ev : c->batch_done)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
+    if ((e = hipEventCreateWithFlags(&c->ext_done, hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate");
     const size_t npix = (size_t)params->width * params->height;
     if ((e = hipMalloc(&c->d_accum_own, npix * sizeof(float4))) != hipSuccess) return bail(e, "hipMalloc(accum)");
     if ((e = hipMemsetAsync(c->d_accum_own, 0, npix * sizeof(float4), c->stream)) != hipSuccess) return bail(e, "hipMemset(accum)");
@@ -1239,22 +1257,69 @@ int pt_reset_accum(pt_ctx *c) {
     return PT_OK;
 }
 
-int pt_bind_accum(pt_ctx *c, void *device_ptr) {
-    if (!c) return PT_EINVAL;
-    HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, sync_all(c));
-    if (!device_ptr) { c->d_accum = c->d_accum_own; return PT_OK; }
-    if (((uintptr_t)device_ptr & 15u) != 0) return fail(c, PT_EINVAL, "accumulation buffer must be 16-byte aligned");
+/* Hands what a stream holds to the GPU without waiting for it.  A wait or a record alone may stay in the runtime's
+ * batch of the stream until the next launch or query on it; a host that then blocks on something other than a HIP call
+ * (a collective's completion, say) would wait for work the GPU has never been given. */
+static void flush_stream(hipStream_t s) {
+    if (hipStreamQuery(s) != hipSuccess) (void)hipGetLastError();
+}
+
+/* an image buffer of the caller's: 16-byte aligned device memory of the context's GPU */
+static int check_image_pointer(pt_ctx *c, void *device_ptr) {
+    if (((uintptr_t)device_ptr & 15u) != 0) return fail(c, PT_EINVAL, "image buffer must be 16-byte aligned");
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, device_ptr);
     if (e != hipSuccess) { (void)hipGetLastError(); return fail(c, PT_EINVAL, "pointer is not known to the HIP runtime"); }
     if (attr.type != hipMemoryTypeDevice || attr.device != c->device)
         return fail(c, PT_EINVAL, "pointer is not device memory of this context's GPU");
+    return PT_OK;
+}
+
+int pt_bind_accum(pt_ctx *c, void *device_ptr) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, sync_all(c));
+    if (!device_ptr) { c->d_accum = c->d_accum_own; return PT_OK; }
+    int rc = check_image_pointer(c, device_ptr);
+    if (rc) return rc;
     c->d_accum = (float4 *)device_ptr;
     return PT_OK;
 }
 
+int pt_next_render_output(pt_ctx *c, void *device_ptr, uint32_t move) {
+    if (!c) return PT_EINVAL;
+    if (!device_ptr) { c->next_out = nullptr; c->next_move = false; return PT_OK; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = check_image_pointer(c, device_ptr);
+    if (rc) return rc;
+    if (device_ptr == (void *)c->d_accum) return fail(c, PT_EINVAL, "the second output is the accumulation buffer itself");
+    c->next_out = (float4 *)device_ptr;
+    c->next_move = move != 0;
+    return PT_OK;
+}
+
 void *pt_accum_device_ptr(pt_ctx *c) { return c ? (void *)c->d_accum : nullptr; }
+
+int pt_accum_release(pt_ctx *c, void *hip_stream) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    /* every operation on the buffer waits for the one before it, so the last mark stands for all of them */
+    if (c->accum_last >= 0) {
+        HIP_TRY(c, hipStreamWaitEvent((hipStream_t)hip_stream, c->slot[c->accum_last].accum_done, 0));
+        flush_stream(c->slot[c->accum_last].stream);
+        flush_stream((hipStream_t)hip_stream);
+    }
+    return PT_OK;
+}
+
+int pt_accum_acquire(pt_ctx *c, void *hip_stream) {
+    if (!c) return PT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipEventRecord(c->ext_done, (hipStream_t)hip_stream));
+    flush_stream((hipStream_t)hip_stream);
+    c->ext_pending = true;
+    return PT_OK;
+}
 
 int pt_primary_hits(pt_ctx *c, int32_t *prim_id, float *distance) {
     if (!c) return PT_EINVAL;
@@ -1420,6 +1485,7 @@ void pt_destroy(pt_ctx *c) {
     dev_free(c->d_refit_order); dev_free(c->d_tri9); dev_free(c->d_refit_flag);
     for (BatchSlot &b : c->slot) slot_release(b);
     for (hipEvent_t &ev : c->batch_done) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    if (c->ext_done) { (void)hipEventDestroy(c->ext_done); c->ext_done = nullptr; }
     c->stream = nullptr;
     delete c;
 }

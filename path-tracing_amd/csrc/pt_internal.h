@@ -117,6 +117,8 @@ struct PTKernelParams {
     const float *spheres;
     const uint32_t *big_leaf_count;
     float4 *accum;
+    float4 *mirror;                /* resolve kernel: the folded image also goes here (pt_next_render_output), or null */
+    uint32_t mirror_move;          /* ... and the accumulation buffer is left holding zeros */
     PTHitRecord *hits;
     PTControl *ctrl;
     uint32_t *spill;               /* path kernel: traversal-stack entries beyond the LDS part, entry k of lane g at spill[k*spill_stride + g] */

@@ -1284,6 +1284,18 @@ __global__ __launch_bounds__(PT_PATH_BLOCK) PT_PATH_OCCUPANCY void path_kernel_m
  * the path kernel (six waves of 80 registers per SIMD) no wave of any other kernel becomes resident, not even one of 8
  * registers (tools/corun_probe.py): this kernel then runs when that grid begins to drain, which is when the batch that waits
  * for it can start anyway.  Beside the smaller grids that short batches get it runs at once. */
+/* A pixel's folded value goes to the accumulation buffer and, for the last batch of a call that has a second output
+ * (pt_next_render_output), there as well - or there INSTEAD, the accumulation buffer being left at zero for the next sum. */
+__device__ __forceinline__ void resolve_store(const PTKernelParams &P, uint32_t pixel, V3 acc) {
+    const float4 v = make_float4(acc.x, acc.y, acc.z, 0.0f);
+    if (P.mirror) {
+        P.mirror[pixel] = v;
+        P.accum[pixel] = P.mirror_move ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : v;
+    } else {
+        P.accum[pixel] = v;
+    }
+}
+
 __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
     __builtin_amdgcn_s_setprio(3);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1303,7 +1315,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
             }
             acc = fold_frame(P, acc, sum, P.frame_first + b * P.frame_stride);
         }
-        P.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        resolve_store(P, pixel, acc);
     }
     if (t < P.width * P.height && P.pixel_hit[t] == PT_PIXEL_MISS) {
         float4 a4 = P.accum[t];
@@ -1311,8 +1323,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(PTKernelParams P) {
         float4 c = P.pixel_const[t];
         for (uint32_t b = 0; b < P.batch_frames; b++)
             acc = fold_frame(P, acc, mk(c.x, c.y, c.z), P.frame_first + b * P.frame_stride);
-        P.accum[t] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+        resolve_store(P, t, acc);
     }
+    /* pixels of other ranks' shards: nothing to fold, but a second output must not keep what an earlier use left there */
+    if (P.mirror && t < P.width * P.height && P.pixel_hit[t] == PT_PIXEL_NOT_MINE) P.mirror[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 __global__ __launch_bounds__(256) void scale_kernel(float4 *accum, uint32_t n, float s) {

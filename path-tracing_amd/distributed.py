@@ -127,16 +127,22 @@ class ShardedRenderer:
         torch.cuda.synchronize()
         renderer.bind_accum(self.owned.data_ptr())
         self.last_timing = {}           # seconds of the last render(): kernels, collective
+        self._side = None               # render_async(): side stream, staging tensors and collectives in flight
+        self._result = None             # ... and the tensor that holds the last result after finish()
+        self._k = 0
 
     def render(self, first_frame, n_frames):
         import time
 
         import torch
 
+        self.finish()                 # renders of render_async() still in flight come first
+        self._result = None
         if self.mode == "frames":
             if first_frame != 0:
                 raise ValueError("frame sharding sums whole renders: first_frame must be 0 (use mode='pixels' to continue a render)")
             self.r.reset_accum()      # zeroes the bound buffer on the library's stream, ordered before the render
+            self._bound_is_clean = False      # it will hold this render's image
         t0 = time.perf_counter()
 
         def all_reduce():
@@ -155,5 +161,116 @@ class ShardedRenderer:
                            lambda s: self.r.scale_accum(s), first_frame, n_frames, self.rank, self.world_size)
             self.r.synchronize()
 
+    # ---- renders in flight: no wait on the host between a render, its collective and the next render ----
+    #
+    # render() above ends every step with a wait: kernels, then the collective, then the host goes on.  At N GPUs a
+    # rank's share of a render is short, the persistent path kernel's drain (about a millisecond in which most of the
+    # GPU idles) is a large part of it, and the collective adds to it.  render_async() only enqueues.  The render's
+    # last frame fold writes the image to one of two staging tensors as well (pt_next_render_output; in frames mode
+    # it MOVES it there, so the next sum starts from zeros): no copy kernel, no clearing.  A side stream waits for
+    # that fold (pt_accum_release) and starts the collective on the staging tensor as an asynchronous operation; the
+    # fold that will write this staging tensor again, two calls later, waits for the side stream (pt_accum_acquire),
+    # which has by then waited for the collective.  The next render's path kernel, which touches neither buffer,
+    # starts while this one drains and while the collective runs.  Every rank issues the same collectives in the same
+    # order.  Results equal render()'s bit for bit (the same sum over ranks, then the same scale).
+    # (A copy of the bound buffer by a kernel or memcpy on the side stream was measured first: a third kernel that must
+    # find room beside two persistent grids, on the critical path between two frame folds, cost 0.3 to 1.2 ms per
+    # step, more than the steps in flight gain.)
+
+    def _side_stream(self):
+        import torch
+
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+            self._staging = [torch.zeros_like(self.buffer), torch.zeros_like(self.buffer)]
+            self._inflight = [None, None]       # per staging tensor: (work handle or None, scale or None)
+            self._k = 0
+            self._bound_is_clean = False        # frames mode: the bound buffer holds zeros
+            torch.cuda.synchronize()            # the zero fills ran on torch's stream; the library writes from its own
+        return self._side
+
+    def _settle(self, j):
+        """The collective that was started on staging tensor j is waited for (by the side stream, not by the host, when
+        the backend allows) and its result is scaled; the tensor may then be read or written again on the side stream."""
+        import torch
+
+        pending = self._inflight[j]
+        if pending is None:
+            return
+        work, scale = pending
+        with torch.cuda.stream(self._side):
+            if work is not None:
+                work.wait()
+            if scale is not None:
+                self._staging[j].mul_(scale)
+        self._inflight[j] = None
+
+    def render_async(self, first_frame, n_frames):
+        """render() without a wait on the host: enqueues the render and the collective, and returns.  finish() waits
+        for everything; image() then holds the result of the LAST call."""
+        import torch
+        import torch.distributed as dist
+
+        side = self._side_stream()
+        handle = side.cuda_stream
+        if n_frames < 1:
+            raise ValueError("a render has at least one frame")
+        j = self._k & 1
+        self._k += 1
+        self._settle(j)                                   # the collective that used this staging tensor two calls ago
+        self.r.accum_acquire(handle)                      # ... must be over before this render's last fold writes it
+        rendered = True
+        if self.mode == "frames":
+            if first_frame != 0:
+                raise ValueError("frame sharding sums whole renders: first_frame must be 0 (use mode='pixels' to continue a render)")
+            if not self._bound_is_clean:
+                self.r.reset_accum()
+                self._bound_is_clean = True
+            first, count, stride = shard_frames(first_frame, n_frames, self.rank, self.world_size)
+            if count:
+                self.r.next_render_output(self._staging[j].data_ptr(), move=True)
+                self.r.render_frames_sum(first, count, stride)
+            rendered = count > 0
+        else:
+            self.r.next_render_output(self._staging[j].data_ptr(), move=False)
+            self.r.render_frames(first_frame, n_frames)
+        self.r.accum_release(handle)                      # the side stream waits for the frame folds of this render
+        with torch.cuda.stream(side):
+            if not rendered:
+                self._staging[j].zero_()                  # more ranks than frames: this rank adds nothing
+            work = None
+            if self.world_size > 1 or self.force_collective:
+                if not dist.is_initialized():
+                    raise RuntimeError("a render sharded over %d ranks needs an initialised torch.distributed process group" % self.world_size)
+                if dist.get_world_size(self.group) != self.world_size:
+                    raise ValueError("the render is sharded over %d ranks but the process group has %d"
+                                     % (self.world_size, dist.get_world_size(self.group)))
+                if dist.get_backend(self.group) != "nccl":
+                    # A backend that works on the host (gloo: the rehearsal of this path with two ranks on one GPU)
+                    # waits for the tensor on a stream of its own and has its caller wait on the HOST for the result.
+                    # Chains of waits between streams that nobody has handed to the GPU yet then never run: seen as a
+                    # hang of both ranks in work.wait(), one run in five.  Such a backend gets the finished image.
+                    side.synchronize()
+                if self.collective == "reduce":
+                    work = dist.reduce(self._staging[j], dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                                       op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                else:
+                    work = dist.all_reduce(self._staging[j], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._inflight[j] = (work, 1.0 / float(n_frames) if self.mode == "frames" else None)
+        self._last = j
+
+    def finish(self):
+        """Waits for every render_async() so far; afterwards image() is the result of the last one."""
+        if self._side is None or self._k == 0:
+            return
+        for j in ((self._last ^ 1), self._last):          # the older one first: same order on every rank
+            self._settle(j)
+        self._side.synchronize()
+        self.r.synchronize()
+        self._result = self._staging[self._last]
+
     def image(self):
-        return self.buffer.view(self.r.height, self.r.width, 4)
+        """The image of the last render() or, after finish(), of the last render_async() (on rank 0 of the group only
+        when the collective is "reduce")."""
+        t = self._result if self._result is not None else self.buffer
+        return t.view(self.r.height, self.r.width, 4)

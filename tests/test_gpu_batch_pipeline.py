@@ -280,3 +280,112 @@ def test_random_call_sequences_with_and_without_the_batch_slots():
                          capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     assert "all equal" in res.stdout
+
+
+def test_accumulation_buffer_handed_to_a_caller_stream_and_back(pkg, scenes, oracle_shared):
+    """pt_accum_release / pt_accum_acquire: renders, copies of their images on a stream of the caller's and (every
+    other time) a clearing of the buffer by that stream, enqueued without one wait on the host.  Every copy must hold
+    exactly the image of its render: a copy that ran early would miss frames, a frame fold that ran before the copy
+    (or the clearing) of the render before it would spoil that copy or its own image."""
+    import torch
+    cfg, tris, bvh, spheres = _setup(scenes)
+    pos, rot = cfg["camera_position"], cfg["camera_rotation"]
+    counts = [1, 3, 2, 3, 1, 2, 3, 1]
+    want = {n: _oracle_frames(oracle_shared, spheres, tris, bvh, pos, rot, 0, n) for n in set(counts)}
+    op = oracle_shared.default_params(**KW)
+    sc = oracle_shared.scene(spheres, tris, bvh)
+    want_sum = {n: oracle_shared.render_frames_sum(op, sc, pos, rot, 0, n, 1) for n in set(counts)}
+    with _renderer(pkg) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        bound = torch.zeros(KW["height"] * KW["width"] * 4, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        r.bind_accum(bound.data_ptr())
+        side = torch.cuda.Stream()
+        copies = [torch.empty_like(bound) for _ in counts]
+        # running mean: frame 0 overwrites, so no clearing is needed between renders
+        for n, out in zip(counts, copies):
+            r.render_frames(0, n)
+            r.accum_release(side.cuda_stream)
+            with torch.cuda.stream(side):
+                out.copy_(bound)
+            r.accum_acquire(side.cuda_stream)
+        r.synchronize()             # waits for the caller's stream up to the last acquire as well
+        for n, out in zip(counts, copies):
+            got = out.cpu().numpy().reshape(KW["height"], KW["width"], 4)
+            assert np.array_equal(bits(got[..., :3]), bits(want[n][..., :3])), n
+        # sums: every render adds to a buffer the caller's stream has cleared behind its copy
+        with torch.cuda.stream(side):
+            bound.zero_()
+        r.accum_acquire(side.cuda_stream)
+        for n, out in zip(counts, copies):
+            r.render_frames_sum(0, n, 1)
+            r.accum_release(side.cuda_stream)
+            with torch.cuda.stream(side):
+                out.copy_(bound)
+                bound.zero_()
+            r.accum_acquire(side.cuda_stream)
+        r.synchronize()
+        for n, out in zip(counts, copies):
+            got = out.cpu().numpy().reshape(KW["height"], KW["width"], 4)
+            assert np.array_equal(bits(got[..., :3]), bits(want_sum[n][..., :3])), n
+        assert float(bound.abs().max().item()) == 0.0
+        r.bind_accum(None)
+
+
+@pytest.mark.parametrize("env", [{}, {"PT_MAX_BATCH": "1"}], ids=["one-batch", "one-frame-batches"])
+def test_second_output_of_a_render_call(pkg, scenes, oracle_shared, env):
+    """pt_next_render_output: the call's last frame fold writes the image to a buffer of the caller's too.  Copy: both
+    buffers hold the running mean.  Move (sum renders): the second buffer holds the sum, the accumulation buffer zeros,
+    so the next sum needs no clearing; the request holds for one call.  Pixels of other ranks' shards come out as
+    zeros whatever the buffer held."""
+    import torch
+    cfg, tris, bvh, spheres = _setup(scenes)
+    pos, rot = cfg["camera_position"], cfg["camera_rotation"]
+    op = oracle_shared.default_params(**KW)
+    sc = oracle_shared.scene(spheres, tris, bvh)
+    mean3 = oracle_shared.render_frames(op, sc, pos, rot, 0, 3)
+    sum3 = oracle_shared.render_frames_sum(op, sc, pos, rot, 0, 3, 1)
+    sum2 = oracle_shared.render_frames_sum(op, sc, pos, rot, 1, 2, 2)
+    shape = (KW["height"], KW["width"], 4)
+    with _renderer(pkg, env) as r:
+        r.upload_scene(spheres, tris, bvh)
+        r.set_camera(pos, rot)
+        out = torch.full((KW["height"] * KW["width"] * 4,), 7.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        r.next_render_output(out.data_ptr())
+        r.render_frames(0, 3)
+        r.synchronize()
+        got = out.cpu().numpy().reshape(shape)
+        assert np.array_equal(bits(got[..., :3]), bits(mean3[..., :3]))
+        assert np.array_equal(bits(r.read_accum(4)[..., :3]), bits(mean3[..., :3]))
+        # the request was for that call only
+        out.fill_(7.0); torch.cuda.synchronize()
+        r.render_frames(0, 1)
+        r.synchronize()
+        assert float(out.min().item()) == 7.0
+        # sums that move: two in a row without a clearing in between
+        r.reset_accum()
+        for want, (first, n, stride) in ((sum3, (0, 3, 1)), (sum2, (1, 2, 2))):
+            r.next_render_output(out.data_ptr(), move=True)
+            r.render_frames_sum(first, n, stride)
+            r.synchronize()
+            got = out.cpu().numpy().reshape(shape)
+            assert np.array_equal(bits(got[..., :3]), bits(want[..., :3]))
+            assert not r.read_accum(4).any()
+        # a shard: the other ranks' pixels are written as zeros
+        from path_tracing_amd.distributed import owner_mask
+        r.set_pixel_shard(1, 3)
+        out.fill_(7.0); torch.cuda.synchronize()
+        r.next_render_output(out.data_ptr())
+        r.render_frames(0, 3)
+        r.synchronize()
+        got = out.cpu().numpy().reshape(shape)
+        mine = owner_mask(KW["width"], KW["height"], 1, 3)
+        assert np.array_equal(bits(got[mine][:, :3]), bits(mean3[mine][:, :3]))
+        assert not got[~mine].any()
+        # refused: the accumulation buffer itself, a host pointer
+        with pytest.raises(pkg.PtError):
+            r.next_render_output(r.accum_device_ptr())
+        with pytest.raises(pkg.PtError):
+            r.next_render_output(np.zeros(16, np.float32).ctypes.data)

@@ -107,7 +107,7 @@ def test_other_configurations_have_a_roofline_from_their_own_counter_pass(cfg_no
 def test_bench_under_the_launcher_with_a_one_rank_rccl_group(shard):
     """What the driver does for N > 1 (torch.distributed.run, backend nccl, ShardedRenderer, max over ranks, per-rank
     report), with the only group a one-GPU box allows: one rank (PT_BENCH_FORCE_GROUP=1)."""
-    env = dict(os.environ, PT_BENCH_FORCE_GROUP="1")
+    env = dict(os.environ, PT_BENCH_FORCE_GROUP="1", PT_BENCH_WATCHDOG_S="120")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--config", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", shard],
@@ -117,13 +117,14 @@ def test_bench_under_the_launcher_with_a_one_rank_rccl_group(shard):
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert len(d["per_rank"]) == 1 and d["per_rank"][0]["rank"] == 0 and d["per_rank"][0]["path_ms_per_step"] > 0
     assert d["collective_ms_per_step"] >= 0 and "predicted_efficiency" in d
+    assert d["splits"][shard]["image_checksum_equal"] is True and d["splits"][shard]["synchronous"]["value"] > 0
 
 
 def test_plain_bench_command_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (as a child,
     before it has touched the GPU) and passes the one JSON line through.  A one-GPU box cannot hold two RCCL ranks, so
     both ranks share GPU 0 and talk over gloo here (PT_BENCH_REHEARSAL=1: the code path, not the numbers)."""
-    env = dict(os.environ, PT_BENCH_REHEARSAL="1")
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1", PT_BENCH_WATCHDOG_S="120")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--steps", "2",
@@ -138,3 +139,9 @@ def test_plain_bench_command_starts_its_own_ranks():
     assert set(d["splits"]) == {"frames", "pixels"} and d["value"] == d["splits"]["frames"]["value"]
     assert "samples per pixel split" in d["config"]["parallelism"]
     assert all(len(s["per_rank"]) == 2 for s in d["splits"].values())
+    # every split is timed with its steps in flight (the value) and with a wait after every step; same image either way
+    assert d["step_protocol"].startswith("steps in flight")
+    for s in d["splits"].values():
+        assert s["synchronous"]["value"] > 0 and len(s["synchronous"]["per_rank"]) == 2
+        assert all(p["collective_ms_per_step"] >= 0 and p["render_ms_per_step"] > 0 for p in s["synchronous"]["per_rank"])
+        assert s["image_checksum_equal"] is True

@@ -23,6 +23,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_frames, out_dir, mode):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)      # a rank that hangs says where, and ends
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -53,7 +55,18 @@ def _worker(rank, world, port, n_frames, out_dir, mode):
             except ValueError:
                 pass
         img = sh.image().cpu().numpy()
+        # the same renders without a wait on the host in between (render_async / finish), then a plain render again
+        if mode == "pixels":
+            sh.render_async(0, n_frames); sh.render_async(0, 2); sh.render_async(2, n_frames - 2)
+        else:
+            sh.render_async(0, 2); sh.render_async(0, n_frames); sh.render_async(0, n_frames)
+        sh.finish()
+        img_async = sh.image().cpu().numpy()
+        sh.render(0, n_frames)
+        img_after = sh.image().cpu().numpy()
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), img)
+    np.save(os.path.join(out_dir, "rank%d_async.npy" % rank), img_async)
+    np.save(os.path.join(out_dir, "rank%d_after.npy" % rank), img_after)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,6 +74,8 @@ def _worker(rank, world, port, n_frames, out_dir, mode):
 def _rccl_worker(rank, port, n_frames, out_dir):
     """One rank, backend nccl: the calls bench.py --gpus N makes (group creation bound to the device, reduce and
     all_reduce on the tensor the library renders into, barrier, all_gather_object) on RCCL itself."""
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -82,6 +97,10 @@ def _rccl_worker(rank, port, n_frames, out_dir):
             sh = ShardedRenderer(r, 0, 1, mode=mode, collective=collective, force_collective=True)
             sh.render(0, n_frames)
             np.save(os.path.join(out_dir, "%s_%s.npy" % (mode, collective)), sh.image().cpu().numpy())
+            # asynchronous collectives on a side stream, as bench.py --gpus N issues them
+            sh.render_async(0, 1); sh.render_async(0, n_frames); sh.render_async(0, n_frames)
+            sh.finish()
+            np.save(os.path.join(out_dir, "%s_%s_async.npy" % (mode, collective)), sh.image().cpu().numpy())
     t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     gathered = [None]
@@ -103,12 +122,13 @@ def test_one_rank_process_group_on_rccl(tmp_path, oracle_shared, scenes):
     sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
     cam, rot = cfg["camera_position"], cfg["camera_rotation"]
     mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
-    for name in ("pixels_reduce", "pixels_all_reduce"):
+    for name in ("pixels_reduce", "pixels_all_reduce", "pixels_reduce_async", "pixels_all_reduce_async"):
         img = np.load(tmp_path / (name + ".npy"))
         assert np.array_equal(img[..., :3].view(np.uint32), mean[..., :3].view(np.uint32)), name
     want = oracle_shared.render_frames_sum(p, sc, cam, rot, 0, n_frames, 1) * np.float32(1.0 / n_frames)
-    img = np.load(tmp_path / "frames_all_reduce.npy")
-    assert np.array_equal(img[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+    for name in ("frames_all_reduce", "frames_all_reduce_async"):
+        img = np.load(tmp_path / (name + ".npy"))
+        assert np.array_equal(img[..., :3].view(np.uint32), want[..., :3].view(np.uint32)), name
 
 
 def test_two_ranks_one_gpu_pixel_shards(tmp_path, oracle_shared, scenes):
@@ -123,6 +143,9 @@ def test_two_ranks_one_gpu_pixel_shards(tmp_path, oracle_shared, scenes):
     sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
     mean = oracle_shared.render_frames(p, sc, cfg["camera_position"], cfg["camera_rotation"], 0, n_frames)
     assert np.array_equal(r0[..., :3].view(np.uint32), mean[..., :3].view(np.uint32))
+    # renders in flight (render_async / finish) and a plain render after them: the same image
+    for name in ("rank0_async.npy", "rank0_after.npy"):
+        assert np.array_equal(np.load(tmp_path / name).view(np.uint32), r0.view(np.uint32)), name
 
 
 def test_two_ranks_one_gpu_frame_shards(tmp_path, oracle_shared, scenes):
@@ -141,3 +164,5 @@ def test_two_ranks_one_gpu_frame_shards(tmp_path, oracle_shared, scenes):
     assert np.array_equal(r0[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
     mean = oracle_shared.render_frames(p, sc, cam, rot, 0, n_frames)
     np.testing.assert_allclose(r0[..., :3], mean[..., :3], rtol=2e-6, atol=1e-7)
+    for name in ("rank0_async.npy", "rank0_after.npy", "rank1_async.npy", "rank1_after.npy"):
+        assert np.array_equal(np.load(tmp_path / name).view(np.uint32), r0.view(np.uint32)), name

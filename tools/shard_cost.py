@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Wall time of one rank's share of a render under both splits (run alone on a GPU, each render followed by the
-synchronisation the collective needs): what bench.py --gpus N would see per rank, without the collective.
+"""Wall time of one rank's share of a render under both splits, run alone on a GPU, without the collective: what
+bench.py --gpus N would see per rank.  Two protocols: every render followed by the wait a synchronous collective needs
+(ShardedRenderer.render), and the steps in flight (ShardedRenderer.render_async: the accumulation buffer handed to a
+side stream that copies it into a staging tensor, no wait on the host).
 usage: tools/shard_cost.py [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,4 +35,33 @@ with pkg.Renderer(p) as r:
                 once()
             ms = (time.perf_counter() - t0) / K * 1e3
             base = base or ms
-            print("%s split, world %d: %.3f ms per render -> efficiency %.1f %% (render time only)" % (split, world, ms, 100 * base / world / ms))
+            # the same share with the steps in flight
+            import torch
+            bound = torch.zeros(cfg["width"] * cfg["height"] * 4, dtype=torch.float32, device="cuda")
+            staging = [torch.empty_like(bound), torch.empty_like(bound)]
+            side = torch.cuda.Stream()
+            torch.cuda.synchronize()
+            r.bind_accum(bound.data_ptr())
+            def flight(k):
+                if split == "pixels":
+                    r.render_frames(0, n)
+                else:
+                    r.render_frames_sum(0, n // world, world)
+                r.accum_release(side.cuda_stream)
+                with torch.cuda.stream(side):
+                    staging[k & 1].copy_(bound)
+                    if split == "frames":
+                        bound.zero_()
+                r.accum_acquire(side.cuda_stream)
+            for k in range(2):
+                flight(k)
+            r.synchronize()
+            t0 = time.perf_counter()
+            for k in range(3 * K):
+                flight(k)
+            r.synchronize()
+            ms_f = (time.perf_counter() - t0) / (3 * K) * 1e3
+            base_f = ms_f if world == 1 else base_f
+            r.bind_accum(None)
+            print("%s split, world %d: waiting after every render %.3f ms -> efficiency %.1f %%; steps in flight %.3f ms -> %.1f %% "
+                  "(render time only)" % (split, world, ms, 100 * base / world / ms, ms_f, 100 * base_f / world / ms_f), flush=True)

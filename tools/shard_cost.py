@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Wall time of one rank's share of a render under both splits, run alone on a GPU, without the collective: what
 bench.py --gpus N would see per rank.  Two protocols: every render followed by the wait a synchronous collective needs
-(ShardedRenderer.render), and the steps in flight (ShardedRenderer.render_async: the accumulation buffer handed to a
-side stream that copies it into a staging tensor, no wait on the host).
+(ShardedRenderer.render), and the steps in flight (ShardedRenderer.render_async: the image written to a staging tensor by the
+render's last frame fold, a side stream made to wait for it, no wait on the host).
 usage: tools/shard_cost.py [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -43,16 +43,14 @@ with pkg.Renderer(p) as r:
             torch.cuda.synchronize()
             r.bind_accum(bound.data_ptr())
             def flight(k):
+                r.accum_acquire(side.cuda_stream)
                 if split == "pixels":
+                    r.next_render_output(staging[k & 1].data_ptr())
                     r.render_frames(0, n)
                 else:
+                    r.next_render_output(staging[k & 1].data_ptr(), move=True)
                     r.render_frames_sum(0, n // world, world)
                 r.accum_release(side.cuda_stream)
-                with torch.cuda.stream(side):
-                    staging[k & 1].copy_(bound)
-                    if split == "frames":
-                        bound.zero_()
-                r.accum_acquire(side.cuda_stream)
             for k in range(2):
                 flight(k)
             r.synchronize()

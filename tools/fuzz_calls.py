@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Random sequences of API calls applied to two contexts, one with the two batch slots and the kept primary pass, one
+"""Random sequences of API calls (renders, sums, renders with a second output handed to a stream of the caller's, camera
+moves, uploads, refits, shards, ...) applied to two contexts, one with the two batch slots and the kept primary pass, one
 with a single stream (PT_PIPELINE=0) and the full grid (PT_ADAPT_GRID=0); after every read the two accumulation buffers
-must hold the same bits (needs a GPU).  usage: tools/fuzz_calls.py [seed] [operations]"""
+(and the two second outputs) must hold the same bits (needs a GPU).  usage: tools/fuzz_calls.py [seed] [operations]"""
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 import __graft_entry__ as entry
 pkg = entry.load_package()
 from path_tracing_amd import scenes
@@ -42,6 +44,10 @@ poses = [(list(cfg["camera_position"]), list(cfg["camera_rotation"])),
 frame = 0
 reads = 0
 log = []
+# second outputs (pt_next_render_output), one per context, and a stream of the caller's that takes part in the hand-over
+outs = [torch.zeros(H * W * 4, dtype=torch.float32, device="cuda") for _ in both]
+side = torch.cuda.Stream()
+torch.cuda.synchronize()
 for k in range(n_ops):
     x = rng.random()
     if x < 0.40:
@@ -56,6 +62,19 @@ for k in range(n_ops):
     elif x < 0.56:
         n = rng.randint(1, 2); op = ("sum", frame, n)
         for r in both: r.render_frames_sum(frame, n, 1)
+        frame += n
+    elif x < 0.585:
+        n = rng.randint(1, 3); move = rng.random() < 0.5; op = ("render+output", frame, n, move)
+        for r, out in zip(both, outs):
+            r.accum_acquire(side.cuda_stream)
+            r.next_render_output(out.data_ptr(), move=move)
+            if move:
+                r.render_frames_sum(frame, n, 1)
+            else:
+                r.render_frames(frame, n)
+            r.accum_release(side.cuda_stream)
+            with torch.cuda.stream(side):
+                out.mul_(1.0)                   # the caller's stream reads and writes the image it was handed
         frame += n
     elif x < 0.60:
         op = ("reset",); frame = 0
@@ -88,7 +107,9 @@ for k in range(n_ops):
         op = ("read",)
         ia, ib = a.read_accum(4), b.read_accum(4)
         reads += 1
-        if not np.array_equal(ia.view(np.uint32), ib.view(np.uint32)):
+        side.synchronize()
+        oa, ob = outs[0].cpu().numpy(), outs[1].cpu().numpy()
+        if not np.array_equal(ia.view(np.uint32), ib.view(np.uint32)) or not np.array_equal(oa.view(np.uint32), ob.view(np.uint32)):
             print("MISMATCH after operation %d; last operations: %s" % (k, log[-12:]))
             sys.exit(1)
     log.append(op)

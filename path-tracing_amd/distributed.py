@@ -245,17 +245,22 @@ class ShardedRenderer:
                 if dist.get_world_size(self.group) != self.world_size:
                     raise ValueError("the render is sharded over %d ranks but the process group has %d"
                                      % (self.world_size, dist.get_world_size(self.group)))
-                if dist.get_backend(self.group) != "nccl":
-                    # A backend that works on the host (gloo: the rehearsal of this path with two ranks on one GPU)
-                    # waits for the tensor on a stream of its own and has its caller wait on the HOST for the result.
-                    # Chains of waits between streams that nobody has handed to the GPU yet then never run: seen as a
-                    # hang of both ranks in work.wait(), one run in five.  Such a backend gets the finished image.
+                # RCCL runs the collective on the GPU, ordered by streams: started here, waited for (by a stream) in _settle.
+                # A backend that works on the host (gloo: the rehearsal of this path with two ranks on one GPU) copies
+                # the tensor on streams of its own from a thread of its own and has its caller wait on the HOST; beside
+                # renders that the main thread keeps enqueuing that hung both ranks in work.wait() one run in five, and
+                # stalled for half a minute in others.  Such a backend gets the finished image and is waited for at once,
+                # as in render().
+                on_gpu = dist.get_backend(self.group) == "nccl"
+                if not on_gpu:
                     side.synchronize()
+                dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
                 if self.collective == "reduce":
-                    work = dist.reduce(self._staging[j], dst=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                                       op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    work = dist.reduce(self._staging[j], dst=dst, op=dist.ReduceOp.SUM, group=self.group, async_op=on_gpu)
                 else:
-                    work = dist.all_reduce(self._staging[j], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    work = dist.all_reduce(self._staging[j], op=dist.ReduceOp.SUM, group=self.group, async_op=on_gpu)
+                if not on_gpu:
+                    work = None
         self._inflight[j] = (work, 1.0 / float(n_frames) if self.mode == "frames" else None)
         self._last = j
 

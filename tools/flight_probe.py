@@ -2,7 +2,7 @@
 """One rank's share of a sharded render (pixel tiles), run alone on a GPU: wall time per render when the host waits after
 every render, when renders are enqueued back to back into the library's own buffer, and when every render is followed
 by the hand-over of a bound buffer to a side stream that copies it, or writes its image to a second output that a side
-stream waits for (the steps of ShardedRenderer.render_async without the collective).  usage: tools/flight_probe.py [--frames] [config] [world ...]   (--frames: the frame split, sums that move)"""
+stream waits for (the steps of ShardedRenderer.render_async without the collective).  usage: tools/flight_probe.py [--frames] [--modes=a,b] [config] [world ...]   (--frames: the frame split, sums that move)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,8 @@ import __graft_entry__ as entry
 pkg = entry.load_package()
 from path_tracing_amd import scenes
 split = "frames" if "--frames" in sys.argv else "pixels"
-argv = [a for a in sys.argv[1:] if a != "--frames"]
+only = [a[len("--modes="):].split(",") for a in sys.argv if a.startswith("--modes=")]
+argv = [a for a in sys.argv[1:] if a != "--frames" and not a.startswith("--modes=")]
 cfg = scenes.config(int(argv[0]) if argv else 4)
 worlds = [int(a) for a in argv[1:]] or [1, 2, 4, 8]
 tris, bvh = scenes.mesh(cfg["mesh"])
@@ -35,6 +36,8 @@ with pkg.Renderer(p) as r:
                 r.render_frames_sum(0, n // world, world)
         out = []
         for name in ("wait", "flight", "flight+copy", "flight+kernelcopy", "flight+handover-only", "flight+second-output"):
+            if only and name not in only[0]:
+                continue
             r.bind_accum(bound.data_ptr() if name != "wait" and name != "flight" else None)
             def step(k):
                 if name == "flight+second-output":      # what ShardedRenderer.render_async enqueues, minus the collective

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$1; LIB=$(cd "$R" && realpath "$2"); VENV=$3
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-count"
+BARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-count --no-exact"
 passes() { # tag
   local tag=$1
   timeout -s KILL 240 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/$tag/pmc_a" -o p -- python3 "$R/bench.py" $BARGS > "$OUT/$tag.a.log" 2>&1 || return 1

@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$1; shift
-BARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-count $*"
+BARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-count --no-exact $*"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 run() { # name, rocprof args...

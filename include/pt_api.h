@@ -243,7 +243,10 @@ void *pt_accum_device_ptr(pt_ctx *ctx);
  *                     calls, which do not touch the buffer, start without waiting.  The calls that
  *                     synchronise (pt_synchronize, pt_read_accum, ...) wait for that work too.
  * A loop  render; release(s); <copy the image on s>; acquire(s)  keeps the next render's kernels
- * running while the copy of this one is still to come. */
+ * running while the copy of this one is still to come.  Both calls also hand what the two streams hold to
+ * the GPU (a stream wait or an event record alone may stay in the runtime's batch until the next launch or
+ * query on its stream, and a host that then blocks outside HIP - in a collective's completion, say - would
+ * wait for work the GPU was never given). */
 int pt_accum_release(pt_ctx *ctx, void *hip_stream);
 int pt_accum_acquire(pt_ctx *ctx, void *hip_stream);
 

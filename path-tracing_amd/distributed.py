@@ -72,6 +72,53 @@ def render_pixel_sharded(render_owned, all_reduce, first_frame, n_frames):
     all_reduce()
 
 
+class StepsInFlight:
+    """Generic driver of renders whose collectives are still running when the next render is enqueued, independent of
+    where the buffers live: the image of call k goes to staging buffer k mod 2, its collective is started and NOT waited
+    for, and is settled (waited for, then scaled) right before that buffer is written again two calls later, or by
+    finish().  Every rank makes the same calls in the same order, so the collectives match up.
+
+    render_into(j):       enqueues the render whose image ends in staging buffer j
+    start_collective(j):  starts the sum of buffer j over the ranks; returns a handle for wait_collective, or None
+    wait_collective(h):   waits for that collective (on a stream or on the host, as the backend has it)
+    scale(j, s):          multiplies buffer j by s, ordered after the collective"""
+
+    def __init__(self, render_into, start_collective, wait_collective, scale):
+        self.render_into, self.start_collective = render_into, start_collective
+        self.wait_collective, self.scale = wait_collective, scale
+        self.pending = [None, None]         # per staging buffer: (handle or None, scale factor or None)
+        self.calls = 0
+        self.last = None                    # staging buffer of the last call
+
+    def settle(self, j):
+        if self.pending[j] is None:
+            return
+        handle, factor = self.pending[j]
+        if handle is not None:
+            self.wait_collective(handle)
+        if factor is not None:
+            self.scale(j, factor)
+        self.pending[j] = None
+
+    def submit(self, factor=None):
+        """One render and its collective; returns the staging buffer it uses."""
+        j = self.calls & 1
+        self.calls += 1
+        self.settle(j)                      # the collective that used this buffer two calls ago
+        self.render_into(j)
+        self.pending[j] = (self.start_collective(j), factor)
+        self.last = j
+        return j
+
+    def finish(self):
+        """Settles everything; returns the staging buffer that holds the last call's image (None: no call yet)."""
+        if self.last is None:
+            return None
+        for j in (self.last ^ 1, self.last):        # the older one first: the same order on every rank
+            self.settle(j)
+        return self.last
+
+
 def combine(buffer, world_size, group=None, collective="all_reduce", force_collective=False):
     """Sums `buffer` (a torch tensor, CPU or GPU) over the `world_size` ranks that share a render.
 
@@ -127,9 +174,9 @@ class ShardedRenderer:
         torch.cuda.synchronize()
         renderer.bind_accum(self.owned.data_ptr())
         self.last_timing = {}           # seconds of the last render(): kernels, collective
-        self._side = None               # render_async(): side stream, staging tensors and collectives in flight
+        self._side = None               # render_async(): side stream, staging tensors and collectives in flight (_flight)
+        self._steps = None
         self._result = None             # ... and the tensor that holds the last result after finish()
-        self._k = 0
 
     def render(self, first_frame, n_frames):
         import time
@@ -177,81 +224,55 @@ class ShardedRenderer:
     # find room beside two persistent grids, on the critical path between two frame folds, cost 0.3 to 1.2 ms per
     # step, more than the steps in flight gain.)
 
-    def _side_stream(self):
-        import torch
-
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-            self._staging = [torch.zeros_like(self.buffer), torch.zeros_like(self.buffer)]
-            self._inflight = [None, None]       # per staging tensor: (work handle or None, scale or None)
-            self._k = 0
-            self._bound_is_clean = False        # frames mode: the bound buffer holds zeros
-            torch.cuda.synchronize()            # the zero fills ran on torch's stream; the library writes from its own
-        return self._side
-
-    def _settle(self, j):
-        """The collective that was started on staging tensor j is waited for (by the side stream, not by the host, when
-        the backend allows) and its result is scaled; the tensor may then be read or written again on the side stream."""
-        import torch
-
-        pending = self._inflight[j]
-        if pending is None:
-            return
-        work, scale = pending
-        with torch.cuda.stream(self._side):
-            if work is not None:
-                work.wait()
-            if scale is not None:
-                self._staging[j].mul_(scale)
-        self._inflight[j] = None
-
-    def render_async(self, first_frame, n_frames):
-        """render() without a wait on the host: enqueues the render and the collective, and returns.  finish() waits
-        for everything; image() then holds the result of the LAST call."""
+    def _flight(self):
         import torch
         import torch.distributed as dist
 
-        side = self._side_stream()
+        if self._side is not None:
+            return self._steps
+        self._side = side = torch.cuda.Stream()
+        self._staging = [torch.zeros_like(self.buffer), torch.zeros_like(self.buffer)]
+        self._bound_is_clean = False        # frames mode: the bound buffer holds zeros
+        torch.cuda.synchronize()            # the zero fills ran on torch's stream; the library writes from its own
         handle = side.cuda_stream
-        if n_frames < 1:
-            raise ValueError("a render has at least one frame")
-        j = self._k & 1
-        self._k += 1
-        self._settle(j)                                   # the collective that used this staging tensor two calls ago
-        self.r.accum_acquire(handle)                      # ... must be over before this render's last fold writes it
-        rendered = True
-        if self.mode == "frames":
-            if first_frame != 0:
-                raise ValueError("frame sharding sums whole renders: first_frame must be 0 (use mode='pixels' to continue a render)")
-            if not self._bound_is_clean:
-                self.r.reset_accum()
-                self._bound_is_clean = True
-            first, count, stride = shard_frames(first_frame, n_frames, self.rank, self.world_size)
-            if count:
-                self.r.next_render_output(self._staging[j].data_ptr(), move=True)
-                self.r.render_frames_sum(first, count, stride)
-            rendered = count > 0
-        else:
-            self.r.next_render_output(self._staging[j].data_ptr(), move=False)
-            self.r.render_frames(first_frame, n_frames)
-        self.r.accum_release(handle)                      # the side stream waits for the frame folds of this render
-        with torch.cuda.stream(side):
+
+        def render_into(j):
+            first_frame, n_frames = self._call
+            self.r.accum_acquire(handle)                  # the collective that used this tensor must be over before the last fold writes it
+            rendered = True
+            if self.mode == "frames":
+                if not self._bound_is_clean:
+                    self.r.reset_accum()
+                    self._bound_is_clean = True
+                first, count, stride = shard_frames(first_frame, n_frames, self.rank, self.world_size)
+                if count:
+                    self.r.next_render_output(self._staging[j].data_ptr(), move=True)
+                    self.r.render_frames_sum(first, count, stride)
+                rendered = count > 0
+            else:
+                self.r.next_render_output(self._staging[j].data_ptr(), move=False)
+                self.r.render_frames(first_frame, n_frames)
+            self.r.accum_release(handle)                  # the side stream waits for the frame folds of this render
             if not rendered:
-                self._staging[j].zero_()                  # more ranks than frames: this rank adds nothing
-            work = None
-            if self.world_size > 1 or self.force_collective:
-                if not dist.is_initialized():
-                    raise RuntimeError("a render sharded over %d ranks needs an initialised torch.distributed process group" % self.world_size)
-                if dist.get_world_size(self.group) != self.world_size:
-                    raise ValueError("the render is sharded over %d ranks but the process group has %d"
-                                     % (self.world_size, dist.get_world_size(self.group)))
-                # RCCL runs the collective on the GPU, ordered by streams: started here, waited for (by a stream) in _settle.
-                # A backend that works on the host (gloo: the rehearsal of this path with two ranks on one GPU) copies
-                # the tensor on streams of its own from a thread of its own and has its caller wait on the HOST; beside
-                # renders that the main thread keeps enqueuing that hung both ranks in work.wait() one run in five, and
-                # stalled for half a minute in others.  Such a backend gets the finished image and is waited for at once,
-                # as in render().
-                on_gpu = dist.get_backend(self.group) == "nccl"
+                with torch.cuda.stream(side):
+                    self._staging[j].zero_()              # more ranks than frames: this rank adds nothing
+
+        def start_collective(j):
+            if not (self.world_size > 1 or self.force_collective):
+                return None
+            if not dist.is_initialized():
+                raise RuntimeError("a render sharded over %d ranks needs an initialised torch.distributed process group" % self.world_size)
+            if dist.get_world_size(self.group) != self.world_size:
+                raise ValueError("the render is sharded over %d ranks but the process group has %d"
+                                 % (self.world_size, dist.get_world_size(self.group)))
+            # RCCL runs the collective on the GPU, ordered by streams: started here, waited for (by a stream) when it is
+            # settled.  A backend that works on the host (gloo: the rehearsal of this path with two ranks on one GPU)
+            # copies the tensor on streams of its own from a thread of its own and has its caller wait on the HOST; beside
+            # renders that the main thread keeps enqueuing that hung both ranks in work.wait() one run in five, and
+            # stalled for half a minute in others.  Such a backend gets the finished image and is waited for at once,
+            # as in render().
+            on_gpu = dist.get_backend(self.group) == "nccl"
+            with torch.cuda.stream(side):
                 if not on_gpu:
                     side.synchronize()
                 dst = dist.get_global_rank(self.group, 0) if self.group is not None else 0
@@ -259,20 +280,40 @@ class ShardedRenderer:
                     work = dist.reduce(self._staging[j], dst=dst, op=dist.ReduceOp.SUM, group=self.group, async_op=on_gpu)
                 else:
                     work = dist.all_reduce(self._staging[j], op=dist.ReduceOp.SUM, group=self.group, async_op=on_gpu)
-                if not on_gpu:
-                    work = None
-        self._inflight[j] = (work, 1.0 / float(n_frames) if self.mode == "frames" else None)
-        self._last = j
+            return work if on_gpu else None
+
+        def wait_collective(work):
+            with torch.cuda.stream(side):
+                work.wait()                               # RCCL: the side stream waits, not the host
+
+        def scale(j, factor):
+            with torch.cuda.stream(side):
+                self._staging[j].mul_(factor)
+
+        self._steps = StepsInFlight(render_into, start_collective, wait_collective, scale)
+        return self._steps
+
+    def render_async(self, first_frame, n_frames):
+        """render() without a wait on the host: enqueues the render and the collective, and returns.  finish() waits
+        for everything; image() then holds the result of the LAST call."""
+        if n_frames < 1:
+            raise ValueError("a render has at least one frame")
+        if self.mode == "frames" and first_frame != 0:
+            raise ValueError("frame sharding sums whole renders: first_frame must be 0 (use mode='pixels' to continue a render)")
+        steps = self._flight()
+        self._call = (first_frame, n_frames)
+        steps.submit(1.0 / float(n_frames) if self.mode == "frames" else None)
 
     def finish(self):
         """Waits for every render_async() so far; afterwards image() is the result of the last one."""
-        if self._side is None or self._k == 0:
+        if self._side is None:
             return
-        for j in ((self._last ^ 1), self._last):          # the older one first: same order on every rank
-            self._settle(j)
+        j = self._steps.finish()
+        if j is None:
+            return
         self._side.synchronize()
         self.r.synchronize()
-        self._result = self._staging[self._last]
+        self._result = self._staging[j]
 
     def image(self):
         """The image of the last render() or, after finish(), of the last render_async() (on rank 0 of the group only

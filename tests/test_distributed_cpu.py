@@ -195,3 +195,84 @@ def test_one_rank_renderers_in_a_larger_job_do_not_talk(tmp_path, pkg):
         assert "sharded over 3 ranks but the process group has 2" in r[k]["mismatch"]
         assert r[k]["solo_ran"] is True and r[k]["solo"] == [10.0 * (k + 1)] * 4
     assert r[0]["extra"] == [7.0] * 4
+
+
+def test_steps_in_flight_settle_a_buffer_before_it_is_written_again(pkg):
+    """StepsInFlight on its own: buffers alternate, the collective on a buffer is waited for (and its result scaled)
+    right before the render that writes that buffer again, finish() settles the older one first."""
+    from path_tracing_amd.distributed import StepsInFlight
+    log = []
+    steps = StepsInFlight(lambda j: log.append(("render", j)), lambda j: log.append(("start", j)) or "h%d" % len(log),
+                          lambda h: log.append(("wait", h)), lambda j, s: log.append(("scale", j, s)))
+    assert steps.finish() is None
+    assert [steps.submit(0.5), steps.submit(0.25), steps.submit(None)] == [0, 1, 0]
+    assert log == [("render", 0), ("start", 0), ("render", 1), ("start", 1),
+                   ("wait", "h2"), ("scale", 0, 0.5), ("render", 0), ("start", 0)]
+    del log[:]
+    assert steps.finish() == 0
+    assert log == [("wait", "h4"), ("scale", 1, 0.25), ("wait", "h8")]          # the last call had no scale
+    assert steps.finish() == 0 and len(log) == 3                                # nothing left to settle
+
+
+def _flight_worker(rank, world, port, n_frames, out_dir):
+    """Frame-sharded renders in flight on CPU: the oracle stands in for the GPU renderer, gloo all-reduces run as
+    asynchronous operations and are waited for two calls later (StepsInFlight, the driver of
+    ShardedRenderer.render_async)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    from path_tracing_amd import scenes
+    from path_tracing_amd.distributed import StepsInFlight, shard_frames
+    oracle = entry.load_oracle_module().Oracle(shared_math=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    staging = [torch.zeros(27, 48, 4, dtype=torch.float32) for _ in range(2)]
+    call = {}
+
+    def render_into(j):
+        first, count, stride = shard_frames(0, call["n"], rank, world)
+        staging[j].zero_()                  # the device moves its sum here and starts the next one from zeros
+        if count:
+            oracle.render_frames_sum(p, sc, cfg["camera_position"], cfg["camera_rotation"], first, count, stride,
+                                     accum=staging[j].numpy(), nthreads=2)
+
+    steps = StepsInFlight(render_into, lambda j: dist.all_reduce(staging[j], async_op=True), lambda w: w.wait(),
+                          lambda j, s: staging[j].mul_(s))
+    images = []
+    for n in (1, n_frames, 2, n_frames):    # rank 1 renders nothing in the first call (more ranks than frames)
+        call["n"] = n
+        j = steps.submit(1.0 / n)
+        images.append((n, j))
+    last = steps.finish()
+    assert last == images[-1][1]
+    np.save(os.path.join(out_dir, "flight%d.npy" % rank), np.stack([staging[last].numpy(), staging[last ^ 1].numpy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_renders_in_flight_match_the_waiting_protocol(tmp_path, oracle_shared, scenes):
+    import torch.multiprocessing as mp
+    n_frames = 5
+    mp.spawn(_flight_worker, args=(2, _free_port(), n_frames, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "flight0.npy"), np.load(tmp_path / "flight1.npy")
+    assert np.array_equal(r0, r1)
+    cfg = scenes.config(1)
+    tris, bvh = scenes.mesh("teapot")
+    p = oracle_shared.default_params(width=48, height=27, rays_per_pixel=2, max_bounce_count=3)
+    sc = oracle_shared.scene(scenes.spheres_for("cfg1"), tris, bvh)
+    cam, rot = cfg["camera_position"], cfg["camera_rotation"]
+
+    def want(n):
+        parts = [oracle_shared.render_frames_sum(p, sc, cam, rot, rank, len(range(rank, n, 2)), 2) if n > rank
+                 else np.zeros((27, 48, 4), F) for rank in range(2)]
+        return (parts[0] + parts[1]) * F(1.0 / n)
+
+    assert np.array_equal(r0[0].view(np.uint32), want(n_frames).view(np.uint32))      # the last call
+    assert np.array_equal(r0[1].view(np.uint32), want(2).view(np.uint32))             # the one before it, in the other buffer

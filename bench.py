@@ -155,15 +155,16 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
-    if os.environ.get("PT_BENCH_WATCHDOG_S"):
-        # a rank that has not finished by then prints the Python stack of every thread and exits (tests of the N > 1
-        # path set this: a hang of two ranks then names its place instead of running into the caller's time limit)
-        import faulthandler
-        faulthandler.dump_traceback_later(int(os.environ["PT_BENCH_WATCHDOG_S"]), exit=True)
-
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    if os.environ.get("PT_BENCH_WATCHDOG_S"):
+        # a rank that has not finished by then prints the Python stack of every thread and exits (tests of the N > 1
+        # path set this: a hang of two ranks then names its place instead of running into the caller's time limit);
+        # started after the imports, which can take minutes in the first process of a fresh machine
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PT_BENCH_WATCHDOG_S"]), exit=True)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -107,7 +107,7 @@ def test_other_configurations_have_a_roofline_from_their_own_counter_pass(cfg_no
 def test_bench_under_the_launcher_with_a_one_rank_rccl_group(shard):
     """What the driver does for N > 1 (torch.distributed.run, backend nccl, ShardedRenderer, max over ranks, per-rank
     report), with the only group a one-GPU box allows: one rank (PT_BENCH_FORCE_GROUP=1)."""
-    env = dict(os.environ, PT_BENCH_FORCE_GROUP="1", PT_BENCH_WATCHDOG_S="120")
+    env = dict(os.environ, PT_BENCH_FORCE_GROUP="1", PT_BENCH_WATCHDOG_S="240")
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", "29617", os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--config", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--shard", shard],
@@ -124,7 +124,7 @@ def test_plain_bench_command_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run itself (as a child,
     before it has touched the GPU) and passes the one JSON line through.  A one-GPU box cannot hold two RCCL ranks, so
     both ranks share GPU 0 and talk over gloo here (PT_BENCH_REHEARSAL=1: the code path, not the numbers)."""
-    env = dict(os.environ, PT_BENCH_REHEARSAL="1", PT_BENCH_WATCHDOG_S="120")
+    env = dict(os.environ, PT_BENCH_REHEARSAL="1", PT_BENCH_WATCHDOG_S="240")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "1", "--steps", "2",

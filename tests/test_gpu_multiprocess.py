@@ -23,13 +23,13 @@ def _free_port():
 
 
 def _worker(rank, world, port, n_frames, out_dir, mode):
-    import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)      # a rank that hangs says where, and ends
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
     pkg = entry.load_package()
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)     # a rank that hangs says where, and ends (armed after the imports)
     from path_tracing_amd import scenes
     from path_tracing_amd.distributed import ShardedRenderer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -74,13 +74,13 @@ def _worker(rank, world, port, n_frames, out_dir, mode):
 def _rccl_worker(rank, port, n_frames, out_dir):
     """One rank, backend nccl: the calls bench.py --gpus N makes (group creation bound to the device, reduce and
     all_reduce on the tensor the library renders into, barrier, all_gather_object) on RCCL itself."""
-    import faulthandler
-    faulthandler.dump_traceback_later(90, exit=True)
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     import __graft_entry__ as entry
     pkg = entry.load_package()
+    import faulthandler
+    faulthandler.dump_traceback_later(150, exit=True)
     from path_tracing_amd import scenes
     from path_tracing_amd.distributed import ShardedRenderer
     os.environ["MASTER_ADDR"] = "127.0.0.1"

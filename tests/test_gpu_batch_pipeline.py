@@ -364,6 +364,11 @@ def test_second_output_of_a_render_call(pkg, scenes, oracle_shared, env):
         r.render_frames(0, 1)
         r.synchronize()
         assert float(out.min().item()) == 7.0
+        # the entry point that allocates nothing honours the request as well
+        r.next_render_output(out.data_ptr())
+        r.render_frames_static(0, 3)
+        r.synchronize()
+        assert np.array_equal(bits(out.cpu().numpy().reshape(shape)[..., :3]), bits(mean3[..., :3]))
         # sums that move: two in a row without a clearing in between
         r.reset_accum()
         for want, (first, n, stride) in ((sum3, (0, 3, 1)), (sum2, (1, 2, 2))):

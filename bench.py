@@ -326,9 +326,9 @@ def main():
                                         "note": "the same steps with a wait after every step's kernels and after its collective"},
                         "image_checksum_equal": chk == chks}
             result["step_protocol"] = ("synchronous: every step waits for its kernels, then for its collective" if args.sync_steps else
-                                       "steps in flight: render, copy to a staging tensor and asynchronous collective of every step are "
-                                       "enqueued without a wait on the host, as the steps of the single-GPU run are; the timed region "
-                                       "ends with a wait for all of them")
+                                       "steps in flight: the render of every step (its last frame fold writes the image to one of two staging "
+                                       "tensors) and the asynchronous collective on that tensor are enqueued without a wait on the host, as "
+                                       "the steps of the single-GPU run are; the timed region ends with a wait for all of them")
             result["per_rank"] = per_rank
             result["splits"] = {m: split_entry(m) for m in modes}
             result["collective_ms_per_step"] = result["splits"][shard_mode]["collective_ms_per_step"]
